@@ -1,0 +1,222 @@
+"""The reference's scenes and cameras (tests/test.rs:89-523 and the camera literals of the
+eight #[test] drivers, :525-838), written against an abstract `api` that exposes the
+reference's constructor names (Sphere, Rect, Lambertian, HittableList, BVHNode, ...).
+
+`api` is either the product host mirror (raytracing_rust_amd.host.Host) or, in tests,
+the CPU oracle binding — the same builder feeds both, so parity runs see identical inputs.
+
+Every `rng.gen::<f64>()` of the reference builders is replaced by `rng.gen()` on an
+explicitly seeded Philox stream (philox.SceneRng, stream_id 2); BVH axes and Perlin
+tables are drawn inside the backend from its own scene stream (stream_id 1), seeded
+with the same scene_seed.  Scenes are reproduced as built by the reference, bugs
+included: nothing here repairs the degenerate light rect of
+final_scene, the z=0 wall of cornell_smoke or the double floor of cornell_box.
+"""
+import os
+
+import numpy as np
+
+from .philox import SceneRng
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+_EARTH = None
+
+
+def earthmap_rgb8():
+    """texture/earthmap.jpg decoded to row-major RGB8 (tests/test.rs:201-205).  The
+    reference decodes with image 0.25.1/zune-jpeg; this uses PIL (libjpeg) — decoders may
+    differ by +-1 LSB per channel: parity unpinned for the texel values."""
+    global _EARTH
+    if _EARTH is None:
+        from PIL import Image
+
+        img = Image.open(os.path.join(_DATA, "earthmap.jpg")).convert("RGB")
+        arr = np.asarray(img, dtype=np.uint8)
+        _EARTH = (np.ascontiguousarray(arr).reshape(-1), img.size[0], img.size[1])
+    return _EARTH
+
+
+def random_scene(api, seed=1):
+    """tests/test.rs:89-163 (20x20 grid: `for a in -10..10`)."""
+    rng = SceneRng(seed)
+    api.seed_scene_rng(seed)
+    origin = np.array([4.0, 0.2, 0.0])
+    world = []
+    checker = api.CheckerTexture(api.SolidTexture(0.2, 0.3, 0.1), api.SolidTexture(0.9, 0.9, 0.9))
+    world.append(api.Sphere((0.0, -1000.0, 0.0), 1000.0, api.Lambertian(checker)))
+    for a in range(-10, 10):
+        for b in range(-10, 10):
+            choose_material = rng.gen()
+            center = np.array([a + 0.9 * rng.gen(), 0.2, b + 0.9 * rng.gen()])
+            d = center - origin
+            if float(np.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])) > 0.9:
+                if choose_material < 0.8:
+                    c1 = center + np.array([0.0, 0.5 * rng.gen(), 0.0])
+                    albedo = api.SolidTexture(rng.gen() * rng.gen(), rng.gen() * rng.gen(), rng.gen() * rng.gen())
+                    world.append(api.MovingSphere(center, c1, 0.0, 1.0, 0.2, api.Lambertian(albedo)))
+                elif choose_material < 0.95:
+                    albedo = api.SolidTexture(0.5 * (1.0 + rng.gen()), 0.5 * (1.0 + rng.gen()),
+                                              0.5 * (1.0 + rng.gen()))
+                    world.append(api.Sphere(center, 0.2, api.Metal(albedo, 0.5 * rng.gen())))
+                else:
+                    world.append(api.Sphere(center, 0.2, api.Dielectric(1.5)))
+    world.append(api.Sphere((0.0, 1.0, 0.0), 1.0, api.Dielectric(1.5)))
+    world.append(api.Sphere((-4.0, 1.0, 0.0), 1.0, api.Lambertian(api.SolidTexture(0.4, 0.2, 0.1))))
+    world.append(api.Sphere((4.0, 1.0, 0.0), 1.0, api.Metal(api.SolidTexture(0.7, 0.6, 0.5), 0.0)))
+    return api.BVHNode(world, 0.0, 1.0)
+
+
+def two_spheres(api, seed=1):
+    """tests/test.rs:165-182"""
+    api.seed_scene_rng(seed)
+    checker = api.CheckerTexture(api.SolidTexture(0.2, 0.3, 0.1), api.SolidTexture(0.9, 0.9, 0.9))
+    world = api.HittableList()
+    world.push(api.Sphere((0.0, -10.0, 0.0), 10.0, api.Lambertian(checker)))
+    world.push(api.Sphere((0.0, 10.0, 0.0), 10.0, api.Lambertian(checker)))
+    return world
+
+
+def two_perlin_spheres(api, seed=1):
+    """tests/test.rs:184-198"""
+    api.seed_scene_rng(seed)
+    noise = api.NoiseTexture(4.0)
+    world = api.HittableList()
+    world.push(api.Sphere((0.0, -1000.0, 0.0), 1000.0, api.Lambertian(noise)))
+    world.push(api.Sphere((0.0, 2.0, 0.0), 2.0, api.Lambertian(noise)))
+    return world
+
+
+def earth(api, seed=1):
+    """tests/test.rs:200-209 — the world is a single Sphere, not a list."""
+    api.seed_scene_rng(seed)
+    data, nx, ny = earthmap_rgb8()
+    return api.Sphere((0.0, 0.0, 0.0), 2.0, api.Lambertian(api.ImageTexture(data, nx, ny)))
+
+
+def simple_light(api, seed=1):
+    """tests/test.rs:211-240"""
+    api.seed_scene_rng(seed)
+    noise = api.NoiseTexture(4.0)
+    world = api.HittableList()
+    world.push(api.Sphere((0.0, -1000.0, 0.0), 1000.0, api.Lambertian(noise)))
+    world.push(api.Sphere((0.0, 2.0, 0.0), 2.0, api.Lambertian(noise)))
+    world.push(api.Sphere((0.0, 7.0, 0.0), 2.0, api.DiffuseLight(api.SolidTexture(4.0, 4.0, 4.0))))
+    world.push(api.Rect(api.PLANE_XY, 3.0, 1.0, 5.0, 3.0, -2.0, api.DiffuseLight(api.SolidTexture(4.0, 4.0, 4.0))))
+    return world
+
+
+def cornell_box(api, seed=1):
+    """tests/test.rs:242-323 — two coincident floors at y=0 and no ceiling, as written."""
+    api.seed_scene_rng(seed)
+    red = api.Lambertian(api.SolidTexture(0.65, 0.05, 0.05))
+    white = api.Lambertian(api.SolidTexture(0.73, 0.73, 0.73))
+    green = api.Lambertian(api.SolidTexture(0.12, 0.45, 0.15))
+    light = api.DiffuseLight(api.SolidTexture(15.0, 15.0, 15.0))
+    world = api.HittableList()
+    world.push(api.FlipNormals(api.Rect(api.PLANE_YZ, 0.0, 0.0, 555.0, 555.0, 555.0, green)))
+    world.push(api.Rect(api.PLANE_YZ, 0.0, 0.0, 555.0, 555.0, 0.0, red))
+    world.push(api.Rect(api.PLANE_ZX, 227.0, 213.0, 332.0, 343.0, 554.0, light))
+    world.push(api.FlipNormals(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 0.0, white)))
+    world.push(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 0.0, white))
+    world.push(api.FlipNormals(api.Rect(api.PLANE_XY, 0.0, 0.0, 555.0, 555.0, 555.0, white)))
+    world.push(api.Traslate(api.Rotate(api.AXIS_Y, api.Cube((0.0, 0.0, 0.0), (165.0, 165.0, 165.0), white), -18.0),
+                            (130.0, 0.0, 65.0)))
+    world.push(api.Traslate(api.Rotate(api.AXIS_Y, api.Cube((0.0, 0.0, 0.0), (165.0, 330.0, 165.0), white), 15.0),
+                            (265.0, 0.0, 295.0)))
+    return world
+
+
+def cornell_smoke(api, seed=1):
+    """tests/test.rs:325-417 — the flipped XY wall sits at k=0 (in front of the camera)."""
+    api.seed_scene_rng(seed)
+    red = api.Lambertian(api.SolidTexture(0.65, 0.05, 0.05))
+    white = api.Lambertian(api.SolidTexture(0.73, 0.73, 0.73))
+    green = api.Lambertian(api.SolidTexture(0.12, 0.45, 0.15))
+    light = api.DiffuseLight(api.SolidTexture(7.0, 7.0, 7.0))
+    world = api.HittableList()
+    world.push(api.FlipNormals(api.Rect(api.PLANE_YZ, 0.0, 0.0, 555.0, 555.0, 555.0, green)))
+    world.push(api.Rect(api.PLANE_YZ, 0.0, 0.0, 555.0, 555.0, 0.0, red))
+    world.push(api.Rect(api.PLANE_ZX, 127.0, 113.0, 432.0, 443.0, 554.0, light))
+    world.push(api.FlipNormals(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 0.0, white)))
+    world.push(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 555.0, white))
+    world.push(api.FlipNormals(api.Rect(api.PLANE_XY, 0.0, 0.0, 555.0, 555.0, 0.0, white)))
+    box1 = api.Traslate(api.Rotate(api.AXIS_Y, api.Cube((0.0, 0.0, 0.0), (165.0, 165.0, 165.0), white), -18.0),
+                        (130.0, 0.0, 65.0))
+    box2 = api.Traslate(api.Rotate(api.AXIS_Y, api.Cube((0.0, 0.0, 0.0), (165.0, 330.0, 165.0), white), 15.0),
+                        (265.0, 0.0, 295.0))
+    world.push(api.ConstantMedium(box1, 0.01, api.SolidTexture(1.0, 1.0, 1.0)))
+    world.push(api.ConstantMedium(box2, 0.01, api.SolidTexture(0.0, 0.0, 0.0)))
+    return world
+
+
+def final_scene(api, seed=1):
+    """tests/test.rs:419-523 — the light rect has x0=147 > x1=123 and is never hit."""
+    rng = SceneRng(seed)
+    api.seed_scene_rng(seed)
+    white = api.Lambertian(api.SolidTexture(0.73, 0.73, 0.73))
+    ground = api.Lambertian(api.SolidTexture(0.48, 0.83, 0.53))
+    world = api.HittableList()
+    box_list1 = []
+    for i in range(20):
+        for j in range(20):
+            w = 100.0
+            x0 = -1000.0 + i * w
+            z0 = -1000.0 + j * w
+            y0 = 0.0
+            x1 = x0 + w
+            y1 = 100.0 * (rng.gen() + 0.01)
+            z1 = z0 + w
+            box_list1.append(api.Cube((x0, y0, z0), (x1, y1, z1), ground))
+    world.push(api.BVHNode(box_list1, 0.0, 1.0))
+    light = api.DiffuseLight(api.SolidTexture(7.0, 7.0, 7.0))
+    world.push(api.Rect(api.PLANE_ZX, 147.0, 412.0, 123.0, 423.0, 554.0, light))
+    center = np.array([400.0, 400.0, 200.0])
+    world.push(api.MovingSphere(center, center + np.array([30.0, 0.0, 0.0]), 0.0, 1.0, 50.0,
+                                api.Lambertian(api.SolidTexture(0.7, 0.3, 0.1))))
+    world.push(api.Sphere((260.0, 150.0, 45.0), 50.0, api.Dielectric(1.5)))
+    world.push(api.Sphere((0.0, 150.0, 145.0), 50.0, api.Metal(api.SolidTexture(0.8, 0.8, 0.9), 10.0)))
+    boundary = api.Sphere((360.0, 150.0, 145.0), 70.0, api.Dielectric(1.5))
+    world.push(boundary)
+    boundary_clone = api.Sphere((360.0, 150.0, 145.0), 70.0, api.Dielectric(1.5))
+    world.push(api.ConstantMedium(boundary_clone, 0.2, api.SolidTexture(0.2, 0.4, 0.9)))
+    boundary = api.Sphere((0.0, 0.0, 0.0), 5000.0, api.Dielectric(1.5))
+    world.push(api.ConstantMedium(boundary, 0.0001, api.SolidTexture(1.0, 1.0, 1.0)))
+    data, nx, ny = earthmap_rgb8()
+    world.push(api.Sphere((400.0, 200.0, 400.0), 100.0, api.Lambertian(api.ImageTexture(data, nx, ny))))
+    world.push(api.Sphere((220.0, 280.0, 300.0), 80.0, api.Lambertian(api.NoiseTexture(0.1))))
+    box_list2 = []
+    for _ in range(1000):
+        box_list2.append(api.Sphere((165.0 * rng.gen(), 165.0 * rng.gen(), 165.0 * rng.gen()), 10.0, white))
+    world.push(api.Traslate(api.Rotate(api.AXIS_Y, api.BVHNode(box_list2, 0.0, 0.1), 15.0), (-100.0, 270.0, 395.0)))
+    return world
+
+
+# camera literals of the #[test] drivers (tests/test.rs:543-554, 582-593, 622-633, 662-673,
+# 702-713, 741-752, 780-791, 819-830): (look_from, look_at, vfov); every driver uses
+# view_up=(0,1,0), focus_dist=10, aperture=0.1, shutter [0,1] and aspect = nx/ny (:47).
+SCENES = {
+    "random_spheres": (random_scene, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0),
+    "two_spheres": (two_spheres, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0),
+    "two_perlin_spheres": (two_perlin_spheres, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0),
+    "earth": (earth, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0),
+    "simple_light": (simple_light, (13.0, 3.0, 3.0), (0.0, 0.0, 0.0), 50.0),
+    "cornell_box": (cornell_box, (278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 40.0),
+    "cornell_smoke": (cornell_smoke, (278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 40.0),
+    "final_scene": (final_scene, (478.0, 278.0, -600.0), (278.0, 278.0, 0.0), 40.0),
+}
+
+
+def set_camera(api, nx, ny, look_from, look_at, view_up=(0.0, 1.0, 0.0), vertical_fov=40.0, focus_dist=10.0,
+               aperture=0.1, time0=0.0, time1=1.0):
+    """tests/test.rs:30-53 (argument order of the reference helper)."""
+    return api.Camera(look_from, look_at, view_up, vertical_fov, float(nx) / float(ny), aperture, focus_dist, time0,
+                      time1)
+
+
+def build(api, name, nx, ny, seed=1):
+    """Returns (camera, world) for one of the reference's eight test scenes."""
+    fn, look_from, look_at, vfov = SCENES[name]
+    world = fn(api, seed)
+    cam = set_camera(api, nx, ny, look_from, look_at, vertical_fov=vfov)
+    return cam, world
