@@ -1,0 +1,235 @@
+/* rtmi.h — C ABI of the MI355X (gfx950) device path for the per-pixel render loop of
+ * DrStiev/raytracing_rust.
+ *
+ * What this boundary replaces.  The reference has no FFI; the seam is the pair
+ *   create_image(ny, nx, ns, cam, world) -> String      (tests/test.rs:55-85)
+ *   color(ray, world, depth) -> Vector3<f64>            (src/color.rs:6-23)
+ * plus everything they call through the traits Hittable (src/hittable.rs:18-21),
+ * Material (src/material.rs:30-33) and Texture (src/texture.rs:4-6).  A host (the C++
+ * mirror in raytracing_rust_amd/host/, or a Rust shim — see INTEGRATION.md) lowers its
+ * object graph into the flat, plain-old-data scene description below and calls
+ * rtmi_render*, which runs the triple loop of create_image on the GPU.
+ *
+ * Conventions: plain pointers and sizes only; inputs are borrowed for the duration of
+ * the call; outputs are caller-allocated; every entry point returns 0 on success or an
+ * RTMI_ERR_* code (message via rtmi_last_error()); nothing throws across the boundary.
+ * A scene handle is immutable after creation and is bound to one device.
+ *
+ * Arithmetic: fp32 on the device under the contract written in DESIGN.md ("fp32
+ * arithmetic contract"); transcendental functions are those of rtmi_math.h; random
+ * numbers are Philox4x32-10 streams keyed by `seed` with counter
+ * (block, sample, pixel = j*nx+i with j counted from the bottom row, 0).
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_ABI_VERSION 1u
+#define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
+#define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
+
+enum { RTMI_OK = 0, RTMI_ERR_INVALID = 1, RTMI_ERR_UNSUPPORTED = 2, RTMI_ERR_DEVICE = 3, RTMI_ERR_NOMEM = 4 };
+
+/* ---- textures: Texture::value (src/texture.rs) -------------------------------- */
+enum { RTMI_TEX_SOLID = 0, RTMI_TEX_CHECKER = 1, RTMI_TEX_NOISE = 2, RTMI_TEX_IMAGE = 3 };
+typedef struct {
+    int32_t kind;
+    int32_t i0; /* CHECKER: odd texture index | NOISE: perlin table index | IMAGE: image index */
+    int32_t i1; /* CHECKER: even texture index */
+    int32_t pad;
+    float f0, f1, f2; /* SOLID: r,g,b | NOISE: f0 = scale */
+    float f3;
+} rtmi_texture; /* 32 B */
+
+/* Perlin tables of one NoiseTexture (src/perlin.rs:59-74): 256 unit vectors + 3 permutations */
+typedef struct {
+    float ranvec[256 * 4]; /* x,y,z,0 */
+    int32_t perm[3 * 256]; /* perm_x, perm_y, perm_z */
+} rtmi_perlin;
+
+typedef struct {
+    uint64_t offset; /* byte offset of row-major RGB8 texels inside image_data */
+    uint32_t nx, ny;
+} rtmi_image;
+
+/* ---- materials: Material::{scatter,emitted} (src/material.rs) ----------------- */
+enum {
+    RTMI_MAT_LAMBERTIAN = 0,
+    RTMI_MAT_METAL = 1,
+    RTMI_MAT_DIELECTRIC = 2,
+    RTMI_MAT_DIFFUSE_LIGHT = 3,
+    RTMI_MAT_ISOTROPIC = 4
+};
+#define RTMI_MATFLAG_NEEDS_UV 1u /* texture tree contains an IMAGE texture */
+typedef struct {
+    int32_t kind;
+    int32_t tex;
+    float param; /* METAL: fuzz (already clamped to <= 1, material.rs:70) | DIELECTRIC: ref_idx */
+    uint32_t flags;
+} rtmi_material; /* 16 B */
+
+/* ---- primitives: SoA planes of float4 ------------------------------------------
+ * plane A[i]: SPHERE/MSPHERE {c0.x, c0.y, c0.z, radius}   (sphere.rs:20-24, 87-94)
+ *             RECT           {x0, y0, x1, y1}             (rect.rs:14-22)
+ *             CUBE           {min.x, min.y, min.z, max.x} (cube.rs:8-12)
+ * plane B[i]: MSPHERE        {c1-c0 (x,y,z), time0}
+ *             RECT           {k, 0, 0, 0}
+ *             CUBE           {max.y, max.z, 0, 0}
+ * meta[i]   : material, flags, inv_dt (MSPHERE: 1/(time1-time0)), type              */
+enum { RTMI_PRIM_SPHERE = 0, RTMI_PRIM_MSPHERE = 1, RTMI_PRIM_RECT = 2, RTMI_PRIM_CUBE = 3 };
+#define RTMI_PRIMFLAG_FLIP 1u /* FlipNormals (hittable.rs:67-88) folded into the primitive */
+#define RTMI_PRIMFLAG_PLANE_SHIFT 8 /* RECT: Plane YZ=0, ZX=1, XY=2 (rect.rs:8-12) in bits 8..9 */
+typedef struct {
+    int32_t material;
+    uint32_t flags;
+    float inv_dt;
+    int32_t type;
+} rtmi_prim_meta; /* 16 B */
+
+/* ---- BVH: BVHNode (src/bvh.rs:9-14) flattened; one record holds BOTH children's boxes.
+ * child >= 0: index of an internal node; child < 0: leaf = 0x80000000 | type<<28 | prim.
+ * The tree topology is the reference's (median split on a random axis, bvh.rs:17-66):
+ * the traversal result (closest hit, ties -> right child, bvh.rs:75-81) depends on it
+ * only through ties and through which boxes prune, both of which are preserved. */
+typedef struct {
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t left, right;
+    int32_t pad[2];
+} rtmi_bvh_node; /* 64 B */
+#define RTMI_LEAF(type, prim) ((int32_t)(0x80000000u | ((uint32_t)(type) << 28) | (uint32_t)(prim)))
+
+/* ---- instance transforms: Traslate (src/traslate.rs), Rotate (src/rotate.rs) ---- */
+enum { RTMI_XF_TRANSLATE = 0, RTMI_XF_ROTATE_X = 1, RTMI_XF_ROTATE_Y = 2, RTMI_XF_ROTATE_Z = 3 };
+typedef struct {
+    int32_t kind;
+    float x, y, z; /* TRANSLATE: offset | ROTATE_*: x = sin(theta), y = cos(theta) */
+} rtmi_xform; /* 16 B */
+
+/* ---- top-level list entries: HittableList (src/hittable.rs:24-47) of
+ *      [FlipNormals][ConstantMedium][Traslate/Rotate chain] geometry
+ * geometry is a run of primitives scanned in order (a nested HittableList, a Cube, a
+ * single primitive) or a BVH.  xforms are listed outermost first. */
+enum { RTMI_ITEM_LIST = 0, RTMI_ITEM_BVH = 1 };
+#define RTMI_ITEMFLAG_FLIP 1u
+#define RTMI_ITEMFLAG_MEDIUM 2u /* ConstantMedium (src/medium.rs): geometry is the boundary */
+typedef struct {
+    int32_t kind;
+    int32_t first;           /* LIST: first primitive | BVH: root node */
+    int32_t count;           /* LIST: number of primitives */
+    uint32_t flags;
+    int32_t xform_first, xform_count;
+    int32_t medium_material; /* MEDIUM: index of the Isotropic phase material (medium.rs:19-24) */
+    float neg_inv_density;   /* MEDIUM: -(1/density) (medium.rs:40) */
+    float root_min[3], root_max[3]; /* BVH: bbox of the root node (bvh.rs:60-64) */
+    int32_t pad[2];
+} rtmi_item; /* 64 B */
+
+typedef struct {
+    uint32_t abi_version; /* RTMI_ABI_VERSION */
+    uint32_t n_items;
+    const rtmi_item *items;
+    uint32_t n_prims;
+    const float *prim_a; /* n_prims * 4 */
+    const float *prim_b; /* n_prims * 4 */
+    const rtmi_prim_meta *prim_meta;
+    uint32_t n_nodes;
+    const rtmi_bvh_node *nodes;
+    uint32_t n_xforms;
+    const rtmi_xform *xforms;
+    uint32_t n_materials;
+    const rtmi_material *materials;
+    uint32_t n_textures;
+    const rtmi_texture *textures;
+    uint32_t n_perlin;
+    const rtmi_perlin *perlin;
+    uint32_t n_images;
+    const rtmi_image *images;
+    const uint8_t *image_data;
+    uint64_t image_bytes;
+    uint32_t max_bvh_depth; /* must be <= RTMI_MAX_BVH_DEPTH */
+} rtmi_scene_desc;
+
+/* Camera state (src/camera.rs:8-18), already derived by Camera::new (camera.rs:21-51) */
+typedef struct {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    float time0, time1, lens_radius;
+} rtmi_camera;
+
+#define RTMI_FLAG_FAST_CULL 1u /* prune BVH subtrees behind the closest hit (same results) */
+typedef struct {
+    uint32_t nx, ny, ns; /* create_image(ny, nx, ns, ..) */
+    uint32_t max_depth;  /* 50 (color.rs:9) */
+    float t_min;         /* 0.001 (color.rs:7) */
+    uint32_t flags;
+    uint64_t seed;
+    uint32_t tile_rank, tile_world; /* this call renders tiles t with t % tile_world == tile_rank */
+    uint32_t spp_chunks;            /* 0 = choose automatically */
+    uint32_t pad;
+} rtmi_render_params;
+
+/* One framebuffer texel: mean linear radiance (before gamma) and the quantised
+ * ir,ig,ib of tests/test.rs:71-78 packed as r | g<<8 | b<<16. */
+typedef struct {
+    float r, g, b;
+    uint32_t rgb8;
+} rtmi_texel; /* 16 B */
+
+typedef struct {
+    double kernel_ms;  /* render + resolve kernels, from HIP events on the launch stream */
+    double render_ms;  /* the render kernel alone */
+    uint64_t samples;  /* camera paths traced by this call */
+    uint32_t tiles, chunks, blocks, reserved;
+} rtmi_stats;
+
+typedef struct rtmi_scene rtmi_scene;
+
+int rtmi_device_count(void);
+const char *rtmi_last_error(void);
+
+/* Copies the description to `device` (hipMemcpy). */
+int rtmi_scene_create(const rtmi_scene_desc *desc, int device, rtmi_scene **out);
+void rtmi_scene_destroy(rtmi_scene *scene);
+
+/* Number of tiles / texels in the tile-packed local framebuffer of this call:
+ * texel index = local_tile * 64 + (ly * 8 + lx), local_tile = tile / tile_world,
+ * tile = ty * tiles_x + tx counted from the TOP-left tile. */
+uint32_t rtmi_local_tiles(const rtmi_render_params *p);
+
+/* Enqueues the render on `stream` (a hipStream_t, may be NULL) and writes
+ * rtmi_local_tiles()*64 texels to the DEVICE buffer d_texels.  Does not synchronise
+ * unless `stats` is non-NULL (then it waits for the kernels to fill kernel_ms). */
+int rtmi_render_device(rtmi_scene *scene, const rtmi_camera *cam, const rtmi_render_params *p, void *d_texels,
+                       void *stream, rtmi_stats *stats);
+
+/* Blocking whole-image render into host buffers (tile_world must be 1):
+ * out_linear_rgb: ny*nx*3 floats, row 0 = top row (reference j = ny-1); may be NULL
+ * out_rgb8:       ny*nx*3 bytes, same order; may be NULL */
+int rtmi_render(rtmi_scene *scene, const rtmi_camera *cam, const rtmi_render_params *p, float *out_linear_rgb,
+                uint8_t *out_rgb8, rtmi_stats *stats);
+
+/* Host-side un-tiling of `tile_world` gathered local buffers (rank-major, each
+ * rtmi_local_tiles(rank 0)*64 texels, i.e. padded to the largest rank) into raster order. */
+int rtmi_untile(const rtmi_render_params *p, const rtmi_texel *gathered, float *out_linear_rgb, uint8_t *out_rgb8);
+
+/* The P3 text of create_image (tests/test.rs:59,79): "P3\n{nx} {ny}\n255\n" then one
+ * "{ir} {ig} {ib}\n" line per pixel.  Returns the bytes written, or the capacity needed
+ * when buf is NULL or cap is too small. */
+size_t rtmi_ppm_p3(uint32_t nx, uint32_t ny, const uint8_t *rgb8, char *buf, size_t cap);
+
+/* Test hooks: evaluate pieces of the arithmetic contract ON THE DEVICE so that parity
+ * tests can compare them bit-for-bit with a host evaluation of rtmi_math.h / Philox.
+ * op: 0 rtmi_sinf(x), 1 rtmi_logf(x), 2 rtmi_atan2f(x,y), 3 rtmi_asinf(x), 4 x/y,
+ * 5 sqrt(x), 6 rtmi_u01(bits of x).  ctr: n*4 words, key: n*2 words, out: n*4 words. */
+int rtmi_probe_math(int op, const float *x, const float *y, float *out, uint32_t n);
+int rtmi_probe_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out, uint32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

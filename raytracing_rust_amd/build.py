@@ -1,0 +1,72 @@
+"""In-tree build of the native libraries (no cmake; hipcc cross-compiles gfx950 without a GPU).
+
+  lib/librtmi.so     HIP kernels + the C ABI of include/rtmi.h       (hipcc --offload-arch=gfx950)
+  lib/librt_host.so  C++ host mirror + its C bindings, links librtmi (g++)
+
+Flags that matter for parity: -ffp-contract=off on both (no implicit FMA), no fast-math
+(IEEE division/sqrt are correctly rounded by default under hipcc).
+"""
+import os
+import shutil
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_DIR = os.path.join(_PKG, "lib")
+INCLUDE = os.path.join(_ROOT, "include")
+
+RTMI_SRC = [os.path.join(_PKG, "csrc", "rtmi_device.hip")]
+HOST_SRC = [os.path.join(_PKG, "host", "rt_host.cpp"), os.path.join(_PKG, "host", "rt_host_c.cpp")]
+RTMI_DEPS = RTMI_SRC + [os.path.join(INCLUDE, "rtmi.h"), os.path.join(INCLUDE, "rtmi_math.h")]
+HOST_DEPS = HOST_SRC + [os.path.join(_PKG, "host", "rt_host.hpp"), os.path.join(INCLUDE, "rtmi.h")]
+
+LIBRTMI = os.path.join(LIB_DIR, "librtmi.so")
+LIBHOST = os.path.join(LIB_DIR, "librt_host.so")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_rtmi(force=False, verbose=False):
+    if not force and not _stale(LIBRTMI, RTMI_DEPS):
+        return LIBRTMI
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+           "-I" + INCLUDE, "-o", LIBRTMI] + RTMI_SRC
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.run(cmd, check=True)
+    return LIBRTMI
+
+
+def build_host(force=False):
+    if not force and not _stale(LIBHOST, HOST_DEPS + [LIBRTMI]):
+        return LIBHOST
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = ["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall",
+           "-fvisibility=hidden", "-I" + INCLUDE, "-o", LIBHOST] + HOST_SRC + [
+               "-L" + LIB_DIR, "-lrtmi", "-Wl,-rpath,$ORIGIN"]
+    subprocess.run(cmd, check=True)
+    return LIBHOST
+
+
+def build_all(force=False, verbose=False):
+    build_rtmi(force, verbose)
+    build_host(force)
+    return LIBRTMI, LIBHOST
+
+
+if __name__ == "__main__":
+    import sys
+
+    build_all(force="--force" in sys.argv, verbose="-v" in sys.argv)
+    print(LIBRTMI)
+    print(LIBHOST)

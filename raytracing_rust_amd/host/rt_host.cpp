@@ -1,0 +1,775 @@
+// rt_host.cpp — implementation of the C++ host mirror (see rt_host.hpp).
+// CPU evaluation restates the reference in f64 (file:line cited per function); lowering
+// produces the flat scene of include/rtmi.h; Camera::render / create_image call the C ABI.
+#include "rt_host.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace rt {
+
+static constexpr double kPi = 3.14159265358979323846264338327950288;
+static constexpr double kFrac2Pi = 0.636619772367581343075535053490057448; // std::f64::consts::FRAC_2_PI
+static constexpr double kF64Max = 1.79769313486231570814527423731704357e+308;
+
+// ---- Philox / host RNG -------------------------------------------------------------------
+void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (uint32_t)p1; c2 = n2; c3 = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void Rng::seed(uint64_t seed, uint32_t sample, uint32_t pixel, uint32_t stream_id) {
+    key_[0] = (uint32_t)seed; key_[1] = (uint32_t)(seed >> 32);
+    ctr_[0] = 0; ctr_[1] = sample; ctr_[2] = pixel; ctr_[3] = stream_id;
+    pos_ = 4;
+}
+uint32_t Rng::next_u32() {
+    if (pos_ == 4) {
+        philox4x32_10(ctr_, key_, buf_);
+        ctr_[0]++;
+        pos_ = 0;
+    }
+    return buf_[pos_++];
+}
+Rng &scene_rng() {
+    static thread_local Rng r = [] { Rng x; x.seed(1, 0, 0, 1); return x; }();
+    return r;
+}
+Rng &render_rng() {
+    static thread_local Rng r = [] { Rng x; x.seed(42, 0, 0, 0); return x; }();
+    return r;
+}
+
+// ---- src/util.rs:4-24 --------------------------------------------------------------------
+Vec3 random_in_unit_sphere() {
+    Rng &rng = render_rng();
+    const Vec3 unit(1.0, 1.0, 1.0);
+    for (;;) {
+        const double x = rng.gen(), y = rng.gen(), z = rng.gen();
+        const Vec3 p = 2.0 * Vec3(x, y, z) - unit;
+        if (p.magnitude_squared() < 1.0) return p;
+    }
+}
+Vec3 random_in_unit_disk() {
+    Rng &rng = render_rng();
+    const Vec3 unit(1.0, 1.0, 0.0);
+    for (;;) {
+        const double x = rng.gen(), y = rng.gen();
+        const Vec3 p = 2.0 * Vec3(x, y, 0.0) - unit;
+        if (p.magnitude_squared() < 1.0) return p;
+    }
+}
+
+// ---- src/aabb.rs:6-18, 31-44 -------------------------------------------------------------
+AABB surrounding_box(const AABB &a, const AABB &b) {
+    return AABB(Vec3(std::fmin(a.min.x, b.min.x), std::fmin(a.min.y, b.min.y), std::fmin(a.min.z, b.min.z)),
+                Vec3(std::fmax(a.max.x, b.max.x), std::fmax(a.max.y, b.max.y), std::fmax(a.max.z, b.max.z)));
+}
+bool AABB::hit(const Ray &ray, double t_min, double t_max) const {
+    for (int a = 0; a < 3; a++) {
+        const double inv_d = 1.0 / ray.direction()[a];
+        double t0 = (min[a] - ray.origin()[a]) * inv_d;
+        double t1 = (max[a] - ray.origin()[a]) * inv_d;
+        if (inv_d < 0.0) std::swap(t0, t1);
+        t_min = std::fmax(t_min, t0);
+        t_max = std::fmin(t_max, t1);
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+// ---- src/hittable.rs:37-64, 78-87 --------------------------------------------------------
+std::optional<HitRecord> HittableList::hit(const Ray &ray, double t_min, double t_max) const {
+    double closest_so_far = t_max;
+    std::optional<HitRecord> hit_anything;
+    for (const auto &h : list_) {
+        if (auto hit = h->hit(ray, t_min, closest_so_far)) {
+            closest_so_far = hit->t;
+            hit_anything = hit;
+        }
+    }
+    return hit_anything;
+}
+std::optional<AABB> HittableList::bounding_box(double t0, double t1) const {
+    if (list_.empty()) return std::nullopt;
+    auto acc = list_[0]->bounding_box(t0, t1);
+    if (!acc) return std::nullopt;
+    for (size_t i = 1; i < list_.size(); i++) {
+        auto b = list_[i]->bounding_box(t0, t1);
+        if (!b) return std::nullopt;
+        acc = surrounding_box(*acc, *b);
+    }
+    return acc;
+}
+std::optional<HitRecord> FlipNormals::hit(const Ray &ray, double t_min, double t_max) const {
+    auto hit = hittable_->hit(ray, t_min, t_max);
+    if (hit) hit->normal = -hit->normal;
+    return hit;
+}
+std::optional<AABB> FlipNormals::bounding_box(double t0, double t1) const { return hittable_->bounding_box(t0, t1); }
+
+// ---- src/sphere.rs -----------------------------------------------------------------------
+static std::pair<double, double> get_sphere_uv(const Vec3 &p) { // :9-15
+    const double phi = std::atan2(p.z, p.x);
+    const double theta = std::asin(p.y);
+    const double u = 1.0 - (phi + kPi) / (2.0 * kPi);
+    const double v = (theta + kFrac2Pi) / kPi; // sic
+    return {u, v};
+}
+static std::optional<HitRecord> sphere_hit(const Vec3 &center, double radius, const Material *mat, const Ray &ray,
+                                           double t_min, double t_max) { // :37-77 / :122-164
+    const Vec3 oc = ray.origin() - center;
+    const double a = ray.direction().dot(ray.direction());
+    const double b = oc.dot(ray.direction());
+    const double c = oc.dot(oc) - radius * radius;
+    const double discriminant = b * b - a * c;
+    if (discriminant > 0.0) {
+        const double sq = std::sqrt(discriminant);
+        for (int root = 0; root < 2; root++) {
+            const double t = root == 0 ? (-b - sq) / a : (-b + sq) / a;
+            if (t < t_max && t > t_min) {
+                HitRecord r;
+                r.t = t;
+                r.p = ray.pointing_at(t);
+                r.normal = (r.p - center) / radius;
+                std::tie(r.u, r.v) = get_sphere_uv(r.normal);
+                r.material = mat;
+                return r;
+            }
+        }
+    }
+    return std::nullopt;
+}
+std::optional<HitRecord> Sphere::hit(const Ray &ray, double t_min, double t_max) const {
+    return sphere_hit(center_, radius_, material_.get(), ray, t_min, t_max);
+}
+std::optional<AABB> Sphere::bounding_box(double, double) const { // :79-84
+    const Vec3 r(radius_, radius_, radius_);
+    return AABB(center_ - r, center_ + r);
+}
+Vec3 MovingSphere::center(double time) const { // :115-118
+    return center0_ + ((time - time0_) / (time1_ - time0_)) * (center1_ - center0_);
+}
+std::optional<HitRecord> MovingSphere::hit(const Ray &ray, double t_min, double t_max) const {
+    return sphere_hit(center(ray.time()), radius_, material_.get(), ray, t_min, t_max);
+}
+std::optional<AABB> MovingSphere::bounding_box(double t0, double t1) const { // :165-174
+    const Vec3 r(radius_, radius_, radius_);
+    return surrounding_box(AABB(center(t0) - r, center(t0) + r), AABB(center(t1) - r, center(t1) + r));
+}
+
+// ---- src/rect.rs -------------------------------------------------------------------------
+static void plane_axes(int plane, int &k, int &a, int &b) { // :40-44 ; Axis uses the same triples (rotate.rs:13-19)
+    if (plane == 0) { k = 0; a = 1; b = 2; }
+    else if (plane == 1) { k = 1; a = 2; b = 0; }
+    else { k = 2; a = 0; b = 1; }
+}
+std::optional<HitRecord> Rect::hit(const Ray &ray, double t_min, double t_max) const { // :39-69
+    int ka, aa, ba;
+    plane_axes((int)plane_, ka, aa, ba);
+    const double t = (k_ - ray.origin()[ka]) / ray.direction()[ka];
+    if (t < t_min || t > t_max) return std::nullopt;
+    const double x = ray.origin()[aa] + t * ray.direction()[aa];
+    const double y = ray.origin()[ba] + t * ray.direction()[ba];
+    if (x < x0_ || x > x1_ || y < y0_ || y > y1_) return std::nullopt;
+    HitRecord r;
+    r.u = (x - x0_) / (x1_ - x0_);
+    r.v = (y - y0_) / (y1_ - y0_);
+    r.t = t;
+    r.p = ray.pointing_at(t);
+    r.normal = Vec3(0, 0, 0);
+    r.normal[ka] = 1.0;
+    r.material = material_.get();
+    return r;
+}
+std::optional<AABB> Rect::bounding_box(double, double) const { // :71-75 (sic: ignores the plane)
+    return AABB(Vec3(x0_, y0_, k_ - 0.0001), Vec3(x1_, y1_, k_ + 0.0001));
+}
+
+// ---- src/cube.rs:15-94 -------------------------------------------------------------------
+Cube::Cube(const Vec3 &p_min, const Vec3 &p_max, MaterialPtr material)
+    : p_min_(p_min), p_max_(p_max), material_(std::move(material)) {
+    sides_.push(std::make_shared<Rect>(Plane::XY, p_min.x, p_min.y, p_max.x, p_max.y, p_max.z, material_));
+    sides_.push(std::make_shared<Rect>(Plane::XY, p_min.x, p_min.y, p_max.x, p_max.y, p_min.z, material_));
+    sides_.push(std::make_shared<Rect>(Plane::ZX, p_min.z, p_min.x, p_max.z, p_max.x, p_max.y, material_));
+    sides_.push(std::make_shared<Rect>(Plane::ZX, p_min.z, p_min.x, p_max.z, p_max.x, p_min.y, material_));
+    sides_.push(std::make_shared<Rect>(Plane::YZ, p_min.y, p_min.z, p_max.y, p_max.z, p_max.x, material_));
+    sides_.push(std::make_shared<Rect>(Plane::YZ, p_min.y, p_min.z, p_max.y, p_max.z, p_min.x, material_));
+}
+std::optional<HitRecord> Cube::hit(const Ray &ray, double t_min, double t_max) const { return sides_.hit(ray, t_min, t_max); }
+std::optional<AABB> Cube::bounding_box(double, double) const { return AABB(p_min_, p_max_); }
+
+// ---- src/traslate.rs:18-32 ---------------------------------------------------------------
+std::optional<HitRecord> Traslate::hit(const Ray &ray, double t_min, double t_max) const {
+    const Ray moved(ray.origin() - offset_, ray.direction(), ray.time());
+    auto hit = hitable_->hit(moved, t_min, t_max);
+    if (hit) hit->p = hit->p + offset_;
+    return hit;
+}
+std::optional<AABB> Traslate::bounding_box(double t0, double t1) const {
+    auto b = hitable_->bounding_box(t0, t1);
+    if (b) { b->min = b->min + offset_; b->max = b->max + offset_; }
+    return b;
+}
+
+// ---- src/rotate.rs:30-118 ----------------------------------------------------------------
+Rotate::Rotate(Axis axis, HittablePtr hittable, double angle) : axis_(axis), hittable_(std::move(hittable)) {
+    const double radians = (kPi / 180.0) * angle;
+    sin_theta_ = std::sin(radians);
+    cos_theta_ = std::cos(radians);
+    bbox_ = hittable_->bounding_box(0.0, 1.0);
+    if (bbox_) {
+        // :36-37 start max at f64::MAX and min at f64::MIN, so no update in :38-76 ever fires
+        bbox_->min = Vec3(-kF64Max, -kF64Max, -kF64Max);
+        bbox_->max = Vec3(kF64Max, kF64Max, kF64Max);
+    }
+}
+std::optional<HitRecord> Rotate::hit(const Ray &ray, double t_min, double t_max) const {
+    int ra, a, b;
+    plane_axes((int)axis_, ra, a, b);
+    Vec3 origin = ray.origin(), direction = ray.direction();
+    origin[a] = cos_theta_ * ray.origin()[a] + sin_theta_ * ray.origin()[b];
+    origin[b] = -sin_theta_ * ray.origin()[a] + cos_theta_ * ray.origin()[b];
+    direction[a] = cos_theta_ * ray.direction()[a] + sin_theta_ * ray.direction()[b];
+    direction[b] = -sin_theta_ * ray.direction()[a] + cos_theta_ * ray.direction()[b];
+    const Ray rotated(origin, direction, ray.time());
+    auto hit = hittable_->hit(rotated, t_min, t_max);
+    if (hit) {
+        Vec3 p = hit->p, n = hit->normal;
+        p[a] = cos_theta_ * hit->p[a] - sin_theta_ * hit->p[b];
+        p[b] = sin_theta_ * hit->p[a] + cos_theta_ * hit->p[b];
+        n[a] = cos_theta_ * hit->normal[a] - sin_theta_ * hit->normal[b];
+        n[b] = sin_theta_ * hit->normal[a] + cos_theta_ * hit->normal[b];
+        hit->p = p;
+        hit->normal = n;
+    }
+    return hit;
+}
+std::optional<AABB> Rotate::bounding_box(double, double) const { return bbox_; }
+
+// ---- src/medium.rs:16-60 -----------------------------------------------------------------
+ConstantMedium::ConstantMedium(HittablePtr boundary, double density, TexturePtr texture)
+    : boundary_(std::move(boundary)), density_(density), phase_function_(std::make_shared<Isotropic>(std::move(texture))) {}
+std::optional<HitRecord> ConstantMedium::hit(const Ray &ray, double t_min, double t_max) const {
+    Rng &rng = render_rng();
+    if (auto hit1 = boundary_->hit(ray, -kF64Max, kF64Max)) {
+        if (auto hit2 = boundary_->hit(ray, hit1->t + 0.0001, kF64Max)) {
+            if (hit1->t < t_min) hit1->t = t_min;
+            if (hit2->t > t_max) hit2->t = t_max;
+            if (hit1->t < hit2->t) {
+                const double distance_inside_boundary = (hit2->t - hit1->t) * ray.direction().norm();
+                const double hit_distance = -(1.0 / density_) * std::log(rng.gen());
+                if (hit_distance < distance_inside_boundary) {
+                    HitRecord r;
+                    r.t = hit1->t + hit_distance / ray.direction().norm();
+                    r.u = 0.0; r.v = 0.0;
+                    r.p = ray.pointing_at(r.t);
+                    r.normal = Vec3(1.0, 0.0, 0.0);
+                    r.material = phase_function_.get();
+                    return r;
+                }
+            }
+        }
+    }
+    return std::nullopt;
+}
+std::optional<AABB> ConstantMedium::bounding_box(double t0, double t1) const { return boundary_->bounding_box(t0, t1); }
+
+// ---- src/bvh.rs:17-93 --------------------------------------------------------------------
+// sort_unstable_by with the reference's Less/Greater-only comparator (:32-36) leaves the
+// order of equal keys unspecified; this mirror sorts stably on `a.min[axis] - b.min[axis] < 0`.
+BVHNode::BVHNode(std::vector<HittablePtr> &hittable, size_t begin, size_t end, double time0, double time1) {
+    const size_t len = end - begin;
+    if (len == 0) throw Panic("BVHNode::new on an empty slice");
+    const uint32_t axis = scene_rng().gen_range(3);
+    std::vector<std::pair<double, HittablePtr>> keyed;
+    keyed.reserve(len);
+    for (size_t i = begin; i < end; i++) {
+        auto b = hittable[i]->bounding_box(time0, time1);
+        if (!b) throw Panic("No bounding box in BVHNode");
+        keyed.emplace_back(b->min[(int)axis], hittable[i]);
+    }
+    std::stable_sort(keyed.begin(), keyed.end(), [](const auto &a, const auto &b) { return a.first - b.first < 0.0; });
+    for (size_t i = 0; i < len; i++) hittable[begin + i] = keyed[i].second;
+    if (len == 1) { left_ = hittable[begin]; right_ = hittable[begin]; }
+    else if (len == 2) { left_ = hittable[begin]; right_ = hittable[begin + 1]; }
+    else {
+        left_ = std::make_shared<BVHNode>(hittable, begin, begin + len / 2, time0, time1);
+        right_ = std::make_shared<BVHNode>(hittable, begin + len / 2, end, time0, time1);
+    }
+    auto lb = left_->bounding_box(time0, time1), rb = right_->bounding_box(time0, time1);
+    if (!lb || !rb) throw Panic("No bounding box in BVHNode");
+    bbox_ = surrounding_box(*lb, *rb);
+}
+std::optional<HitRecord> BVHNode::hit(const Ray &ray, double t_min, double t_max) const {
+    if (bbox_.hit(ray, t_min, t_max)) {
+        auto l = left_->hit(ray, t_min, t_max);
+        auto r = right_->hit(ray, t_min, t_max);
+        if (l && r) return (l->t < r->t) ? l : r;
+        if (l) return l;
+        if (r) return r;
+    }
+    return std::nullopt;
+}
+std::optional<AABB> BVHNode::bounding_box(double, double) const { return bbox_; }
+
+// ---- src/perlin.rs -----------------------------------------------------------------------
+Perlin::Perlin() {
+    Rng &rng = scene_rng();
+    ran_vec_.reserve(256);
+    for (int i = 0; i < 256; i++) { // perlin_generate :12-26
+        const double x = -1.0 + 2.0 * rng.gen(), y = -1.0 + 2.0 * rng.gen(), z = -1.0 + 2.0 * rng.gen();
+        ran_vec_.push_back(Vec3(x, y, z).normalize());
+    }
+    auto perm = [&rng]() { // perlin_generate_perm :28-36 + permute :4-10
+        std::vector<size_t> p(256);
+        for (size_t i = 0; i < 256; i++) p[i] = i;
+        for (int i = 255; i >= 0; i--) std::swap(p[(size_t)i], p[rng.gen_range((uint32_t)i + 1)]);
+        return p;
+    };
+    perm_x_ = perm(); perm_y_ = perm(); perm_z_ = perm();
+}
+static uint64_t as_usize(double x) { // Rust `f64 as usize`
+    if (!(x > 0.0)) return 0;
+    if (x >= 18446744073709551615.0) return UINT64_MAX;
+    return (uint64_t)x;
+}
+double Perlin::noise(const Vec3 &p) const { // :76-97 + perlin_interpolation :38-56
+    const double u = p.x - std::floor(p.x), v = p.y - std::floor(p.y), w = p.z - std::floor(p.z);
+    const uint64_t i = as_usize(std::floor(p.x)), j = as_usize(std::floor(p.y)), k = as_usize(std::floor(p.z));
+    const double uu = u * u * (3.0 - 2.0 * u), vv = v * v * (3.0 - 2.0 * v), ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+    for (uint64_t di = 0; di < 2; di++)
+        for (uint64_t dj = 0; dj < 2; dj++)
+            for (uint64_t dk = 0; dk < 2; dk++) {
+                const Vec3 &c = ran_vec_[perm_x_[(i + di) & 255] ^ perm_y_[(j + dj) & 255] ^ perm_z_[(k + dk) & 255]];
+                const Vec3 weight(u - (double)di, v - (double)dj, w - (double)dk);
+                accum += ((double)di * uu + (double)(1 - di) * (1.0 - uu)) * ((double)dj * vv + (double)(1 - dj) * (1.0 - vv)) *
+                         ((double)dk * ww + (double)(1 - dk) * (1.0 - ww)) * c.dot(weight);
+            }
+    return accum;
+}
+double Perlin::turb(const Vec3 &p, size_t depth) const { // :99-109
+    double accum = 0.0, weight = 1.0;
+    Vec3 temp_p = p;
+    for (size_t i = 0; i < depth; i++) {
+        accum += weight * noise(temp_p);
+        weight *= 0.5;
+        temp_p = temp_p * 2.0;
+    }
+    return std::fabs(accum);
+}
+
+// ---- src/texture.rs ----------------------------------------------------------------------
+Vec3 SolidTexture::value(double, double, const Vec3 &) const { return color_; }
+Vec3 CheckerTexture::value(double u, double v, const Vec3 &p) const { // :39-48
+    const double s = std::sin(10.0 * p.x) * std::sin(10.0 * p.y) * std::sin(10.0 * p.z);
+    return s < 0.0 ? odd_->value(u, v, p) : even_->value(u, v, p);
+}
+Vec3 NoiseTexture::value(double, double, const Vec3 &p) const { // :65-71
+    return Vec3(1.0, 1.0, 1.0) * 0.5 * (1.0 + std::sin(scale_ * p.x + 5.0 * noise_.turb(p, 7)));
+}
+Vec3 ImageTexture::value(double u, double v, const Vec3 &) const { // :86-108
+    const uint64_t nx = nx_, ny = ny_;
+    uint64_t i = as_usize(u * (double)nx), j = as_usize((1.0 - v) * (double)ny);
+    if (i > nx - 1) i = nx - 1;
+    if (j > ny - 1) j = ny - 1;
+    const uint64_t idx = 3 * i + 3 * nx * j;
+    return Vec3(data_[idx] / 255.0, data_[idx + 1] / 255.0, data_[idx + 2] / 255.0);
+}
+
+// ---- src/material.rs ---------------------------------------------------------------------
+static Vec3 reflect(const Vec3 &v, const Vec3 &n) { return v - 2.0 * v.dot(n) * n; } // :9-11
+static std::optional<Vec3> refract(const Vec3 &v, const Vec3 &n, double ni_over_nt) { // :13-23
+    const Vec3 uv = v.normalize();
+    const double dt = uv.dot(n);
+    const double discriminant = 1.0 - ni_over_nt * ni_over_nt * (1.0 - dt * dt);
+    if (discriminant > 0.0) return ni_over_nt * (uv - n * dt) - n * std::sqrt(discriminant);
+    return std::nullopt;
+}
+static double schlick(double cosine, double ref_idx) { // :25-28
+    double r0 = (1.0 - ref_idx) / (1.0 + ref_idx);
+    r0 = r0 * r0;
+    const double x = 1.0 - cosine, x2 = x * x;
+    return r0 + (1.0 - r0) * (x * (x2 * x2));
+}
+std::optional<std::pair<Ray, Vec3>> Lambertian::scatter(const Ray &ray, const HitRecord &hit) const { // :49-53
+    const Vec3 target = hit.p + hit.normal + random_in_unit_sphere();
+    return std::make_pair(Ray(hit.p, target - hit.p, ray.time()), albedo_->value(hit.u, hit.v, hit.p));
+}
+std::optional<std::pair<Ray, Vec3>> Metal::scatter(const Ray &ray, const HitRecord &hit) const { // :75-87
+    Vec3 reflected = reflect(ray.direction().normalize(), hit.normal);
+    if (fuzz_ > 0.0) reflected = reflected + fuzz_ * random_in_unit_sphere();
+    if (reflected.dot(hit.normal) > 0.0)
+        return std::make_pair(Ray(hit.p, reflected, ray.time()), albedo_->value(hit.u, hit.v, hit.p));
+    return std::nullopt;
+}
+std::optional<std::pair<Ray, Vec3>> Dielectric::scatter(const Ray &ray, const HitRecord &hit) const { // :106-126
+    const Vec3 attenuation(1.0, 1.0, 1.0);
+    Vec3 outward_normal;
+    double ni_over_nt, cosine;
+    if (ray.direction().dot(hit.normal) > 0.0) {
+        cosine = ref_idx_ * ray.direction().dot(hit.normal) / ray.direction().magnitude();
+        outward_normal = -hit.normal;
+        ni_over_nt = ref_idx_;
+    } else {
+        cosine = -ray.direction().dot(hit.normal) / ray.direction().magnitude();
+        outward_normal = hit.normal;
+        ni_over_nt = 1.0 / ref_idx_;
+    }
+    if (auto refracted = refract(ray.direction(), outward_normal, ni_over_nt)) {
+        const double reflect_prob = schlick(cosine, ref_idx_);
+        if (render_rng().gen() >= reflect_prob) return std::make_pair(Ray(hit.p, *refracted, ray.time()), attenuation);
+    }
+    return std::make_pair(Ray(hit.p, reflect(ray.direction(), hit.normal), ray.time()), attenuation);
+}
+std::optional<std::pair<Ray, Vec3>> Isotropic::scatter(const Ray &ray, const HitRecord &hit) const { // :165-168
+    return std::make_pair(Ray(hit.p, random_in_unit_sphere(), ray.time()), albedo_->value(hit.u, hit.v, hit.p));
+}
+
+// ---- src/color.rs:6-23 -------------------------------------------------------------------
+Vec3 color(const Ray &ray, const Hittable &world, size_t depth) {
+    if (auto hit = world.hit(ray, 0.001, kF64Max)) {
+        const Vec3 emitted = hit->material->emitted(hit->u, hit->v, hit->p);
+        if (depth < 50) {
+            if (auto sc = hit->material->scatter(ray, *hit))
+                return emitted + sc->second.zip_mul(color(sc->first, world, depth + 1));
+        }
+        return emitted;
+    }
+    return Vec3(0.0, 0.0, 0.0);
+}
+
+// ======================================================================================
+// lowering
+// ======================================================================================
+int Texture::lower(SceneBuilder &) const { throw Unsupported("user-defined Texture cannot be lowered to the device"); }
+int Material::lower(SceneBuilder &) const { throw Unsupported("user-defined Material cannot be lowered to the device"); }
+
+int SceneBuilder::texture_index(const Texture *t) {
+    auto it = tex_ids_.find(t);
+    if (it != tex_ids_.end()) return it->second;
+    const int id = t->lower(*this);
+    tex_ids_[t] = id;
+    return id;
+}
+int SceneBuilder::material_index(const Material *m) {
+    auto it = mat_ids_.find(m);
+    if (it != mat_ids_.end()) return it->second;
+    const int id = m->lower(*this);
+    mat_ids_[m] = id;
+    return id;
+}
+bool SceneBuilder::texture_needs_uv(int tex) const {
+    const rtmi_texture &t = out.textures[(size_t)tex];
+    if (t.kind == RTMI_TEX_IMAGE) return true;
+    if (t.kind == RTMI_TEX_CHECKER) return texture_needs_uv(t.i0) || texture_needs_uv(t.i1);
+    return false;
+}
+int SolidTexture::lower(SceneBuilder &b) const {
+    rtmi_texture t{};
+    t.kind = RTMI_TEX_SOLID; t.f0 = (float)color_.x; t.f1 = (float)color_.y; t.f2 = (float)color_.z;
+    return b.add_texture(t);
+}
+int CheckerTexture::lower(SceneBuilder &b) const {
+    rtmi_texture t{};
+    t.kind = RTMI_TEX_CHECKER;
+    t.i0 = b.texture_index(odd_.get());
+    t.i1 = b.texture_index(even_.get());
+    return b.add_texture(t);
+}
+int NoiseTexture::lower(SceneBuilder &b) const {
+    rtmi_perlin pn{};
+    for (int i = 0; i < 256; i++) {
+        pn.ranvec[4 * i] = (float)noise_.ran_vec_[(size_t)i].x;
+        pn.ranvec[4 * i + 1] = (float)noise_.ran_vec_[(size_t)i].y;
+        pn.ranvec[4 * i + 2] = (float)noise_.ran_vec_[(size_t)i].z;
+        pn.perm[i] = (int32_t)noise_.perm_x_[(size_t)i];
+        pn.perm[256 + i] = (int32_t)noise_.perm_y_[(size_t)i];
+        pn.perm[512 + i] = (int32_t)noise_.perm_z_[(size_t)i];
+    }
+    b.out.perlin.push_back(pn);
+    rtmi_texture t{};
+    t.kind = RTMI_TEX_NOISE; t.i0 = (int32_t)b.out.perlin.size() - 1; t.f0 = (float)scale_;
+    return b.add_texture(t);
+}
+int ImageTexture::lower(SceneBuilder &b) const {
+    if ((size_t)nx_ * ny_ * 3 != data_.size() || nx_ == 0 || ny_ == 0) throw Panic("ImageTexture: data size != 3*nx*ny");
+    rtmi_image im{};
+    im.offset = b.out.image_data.size(); im.nx = nx_; im.ny = ny_;
+    b.out.image_data.insert(b.out.image_data.end(), data_.begin(), data_.end());
+    b.out.images.push_back(im);
+    rtmi_texture t{};
+    t.kind = RTMI_TEX_IMAGE; t.i0 = (int32_t)b.out.images.size() - 1;
+    return b.add_texture(t);
+}
+static int lower_mat(SceneBuilder &b, int kind, const Texture *tex, double param) {
+    rtmi_material m{};
+    m.kind = kind; m.param = (float)param;
+    m.tex = tex ? b.texture_index(tex) : 0;
+    m.flags = (tex && b.texture_needs_uv(m.tex)) ? RTMI_MATFLAG_NEEDS_UV : 0u;
+    return b.add_material(m);
+}
+int Lambertian::lower(SceneBuilder &b) const { return lower_mat(b, RTMI_MAT_LAMBERTIAN, albedo_.get(), 0.0); }
+int Metal::lower(SceneBuilder &b) const { return lower_mat(b, RTMI_MAT_METAL, albedo_.get(), fuzz_); }
+int Dielectric::lower(SceneBuilder &b) const { return lower_mat(b, RTMI_MAT_DIELECTRIC, nullptr, ref_idx_); }
+int DiffuseLight::lower(SceneBuilder &b) const { return lower_mat(b, RTMI_MAT_DIFFUSE_LIGHT, emit_.get(), 0.0); }
+int Isotropic::lower(SceneBuilder &b) const { return lower_mat(b, RTMI_MAT_ISOTROPIC, albedo_.get(), 0.0); }
+
+// strips FlipNormals wrappers (negation commutes exactly with translation and rotation)
+static const Hittable *strip_flips(const Hittable *h, bool &flip) {
+    while (auto f = dynamic_cast<const FlipNormals *>(h)) { flip = !flip; h = f->inner().get(); }
+    return h;
+}
+static bool contains_moving(const Hittable *h) {
+    bool dummy = false;
+    h = strip_flips(h, dummy);
+    if (dynamic_cast<const MovingSphere *>(h)) return true;
+    if (auto n = dynamic_cast<const BVHNode *>(h)) return contains_moving(n->left_.get()) || contains_moving(n->right_.get());
+    return false;
+}
+
+// one primitive -> planes A/B + meta; returns RTMI_LEAF-style type in the high bits of nothing: plain index
+int SceneBuilder::push_prim(const Hittable &h, bool flip, bool force_moving) {
+    float A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
+    rtmi_prim_meta m{};
+    m.flags = flip ? RTMI_PRIMFLAG_FLIP : 0u;
+    m.inv_dt = 0.0f;
+    if (auto s = dynamic_cast<const Sphere *>(&h)) {
+        A[0] = (float)s->center_.x; A[1] = (float)s->center_.y; A[2] = (float)s->center_.z; A[3] = (float)s->radius_;
+        m.material = material_index(s->material_.get());
+        if (force_moving) { // c0 + (time - 0)*1 * 0 == c0 exactly: same bits, one code path in the BVH
+            m.type = RTMI_PRIM_MSPHERE; m.inv_dt = 1.0f;
+        } else {
+            m.type = RTMI_PRIM_SPHERE;
+        }
+    } else if (auto ms = dynamic_cast<const MovingSphere *>(&h)) {
+        const float c0[3] = {(float)ms->center0_.x, (float)ms->center0_.y, (float)ms->center0_.z};
+        const float c1[3] = {(float)ms->center1_.x, (float)ms->center1_.y, (float)ms->center1_.z};
+        const float t0 = (float)ms->time0_, t1 = (float)ms->time1_;
+        A[0] = c0[0]; A[1] = c0[1]; A[2] = c0[2]; A[3] = (float)ms->radius_;
+        B[0] = c1[0] - c0[0]; B[1] = c1[1] - c0[1]; B[2] = c1[2] - c0[2]; B[3] = t0;
+        m.inv_dt = 1.0f / (t1 - t0);
+        m.type = RTMI_PRIM_MSPHERE;
+        m.material = material_index(ms->material_.get());
+    } else if (auto r = dynamic_cast<const Rect *>(&h)) {
+        A[0] = (float)r->x0_; A[1] = (float)r->y0_; A[2] = (float)r->x1_; A[3] = (float)r->y1_;
+        B[0] = (float)r->k_;
+        m.flags |= ((uint32_t)r->plane_) << RTMI_PRIMFLAG_PLANE_SHIFT;
+        m.type = RTMI_PRIM_RECT;
+        m.material = material_index(r->material_.get());
+    } else if (auto c = dynamic_cast<const Cube *>(&h)) {
+        A[0] = (float)c->p_min_.x; A[1] = (float)c->p_min_.y; A[2] = (float)c->p_min_.z; A[3] = (float)c->p_max_.x;
+        B[0] = (float)c->p_max_.y; B[1] = (float)c->p_max_.z;
+        m.type = RTMI_PRIM_CUBE;
+        m.material = material_index(c->material_.get());
+    } else {
+        throw Unsupported("this Hittable cannot be a device primitive (supported: Sphere, MovingSphere, Rect, Cube)");
+    }
+    out.prim_a.insert(out.prim_a.end(), A, A + 4);
+    out.prim_b.insert(out.prim_b.end(), B, B + 4);
+    out.prim_meta.push_back(m);
+    return (int)out.prim_meta.size() - 1;
+}
+
+static void put_box(float mn[3], float mx[3], const AABB &b) {
+    mn[0] = (float)b.min.x; mn[1] = (float)b.min.y; mn[2] = (float)b.min.z;
+    mx[0] = (float)b.max.x; mx[1] = (float)b.max.y; mx[2] = (float)b.max.z;
+}
+
+// BVHNode -> rtmi_bvh_node records in preorder; leaves appended left to right
+int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving) {
+    if (depth > out.max_bvh_depth) out.max_bvh_depth = depth;
+    const int32_t id = (int32_t)out.nodes.size();
+    out.nodes.push_back(rtmi_bvh_node{});
+    int32_t child[2];
+    const Hittable *ch[2] = {n.left_.get(), n.right_.get()};
+    for (int c = 0; c < 2; c++) {
+        bool flip = false;
+        const Hittable *h = strip_flips(ch[c], flip);
+        if (auto sub = dynamic_cast<const BVHNode *>(h)) {
+            if (flip) throw Unsupported("FlipNormals around a BVHNode inside a BVH is not lowered");
+            child[c] = lower_bvh(*sub, depth + 1, force_moving);
+            rtmi_bvh_node &me = out.nodes[(size_t)id];
+            put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, sub->bbox_);
+        } else {
+            const int prim = push_prim(*h, flip, force_moving);
+            child[c] = RTMI_LEAF(out.prim_meta[(size_t)prim].type, prim);
+            // A leaf child has no box test in the reference (bvh.rs:72-73); the box is stored only
+            // for the optional fast-cull prefilter, so it must contain the primitive at EVERY ray
+            // time: exact for static primitives, unbounded for moving spheres.
+            const double big = 3.40282346638528859811704183484516925e+38;
+            AABB lb(Vec3(-big, -big, -big), Vec3(big, big, big));
+            if (!dynamic_cast<const MovingSphere *>(h)) {
+                auto b = h->bounding_box(0.0, 1.0);
+                if (b && !dynamic_cast<const Rect *>(h)) lb = *b; // Rect::bounding_box ignores the plane (rect.rs:72-73)
+            }
+            rtmi_bvh_node &me = out.nodes[(size_t)id];
+            put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, lb);
+        }
+    }
+    out.nodes[(size_t)id].left = child[0];
+    out.nodes[(size_t)id].right = child[1];
+    return id;
+}
+
+void SceneBuilder::lower_item(const Hittable &top) {
+    rtmi_item it{};
+    it.xform_first = (int32_t)out.xforms.size();
+    bool flip = false, medium = false;
+    const Hittable *h = &top;
+    for (;;) { // peel wrappers, outermost first
+        if (auto f = dynamic_cast<const FlipNormals *>(h)) { flip = !flip; h = f->inner().get(); continue; }
+        if (auto m = dynamic_cast<const ConstantMedium *>(h)) {
+            if (medium) throw Unsupported("nested ConstantMedium is not lowered");
+            if (it.xform_count > 0) throw Unsupported("ConstantMedium inside Traslate/Rotate is not lowered");
+            medium = true;
+            it.medium_material = material_index(m->phase_function_.get());
+            it.neg_inv_density = -(1.0f / (float)m->density_);
+            h = m->boundary_.get();
+            continue;
+        }
+        if (auto t = dynamic_cast<const Traslate *>(h)) {
+            rtmi_xform x{};
+            x.kind = RTMI_XF_TRANSLATE; x.x = (float)t->offset_.x; x.y = (float)t->offset_.y; x.z = (float)t->offset_.z;
+            out.xforms.push_back(x); it.xform_count++;
+            h = t->hitable_.get();
+            continue;
+        }
+        if (auto r = dynamic_cast<const Rotate *>(h)) {
+            rtmi_xform x{};
+            x.kind = RTMI_XF_ROTATE_X + (int)r->axis_; x.x = (float)r->sin_theta_; x.y = (float)r->cos_theta_;
+            out.xforms.push_back(x); it.xform_count++;
+            h = r->hittable_.get();
+            continue;
+        }
+        break;
+    }
+    it.flags = (flip ? RTMI_ITEMFLAG_FLIP : 0u) | (medium ? RTMI_ITEMFLAG_MEDIUM : 0u);
+    if (auto bvh = dynamic_cast<const BVHNode *>(h)) {
+        it.kind = RTMI_ITEM_BVH;
+        put_box(it.root_min, it.root_max, bvh->bbox_);
+        it.first = lower_bvh(*bvh, 1, contains_moving(bvh));
+    } else if (auto list = dynamic_cast<const HittableList *>(h)) {
+        it.kind = RTMI_ITEM_LIST;
+        it.first = (int32_t)out.prim_meta.size();
+        for (const auto &e : list->items()) {
+            bool f2 = false;
+            const Hittable *p = strip_flips(e.get(), f2);
+            push_prim(*p, f2, false);
+            it.count++;
+        }
+    } else {
+        it.kind = RTMI_ITEM_LIST;
+        it.first = push_prim(*h, false, false);
+        it.count = 1;
+    }
+    out.items.push_back(it);
+}
+
+void SceneBuilder::lower_world(const Hittable &world) {
+    // world.hit(ray, 0.001, MAX) on a HittableList == the scan the device performs over items;
+    // any other world is a list of one
+    if (auto list = dynamic_cast<const HittableList *>(&world)) {
+        for (const auto &e : list->items()) lower_item(*e);
+        if (list->items().empty()) throw Unsupported("empty world");
+    } else {
+        lower_item(world);
+    }
+    if (out.max_bvh_depth > RTMI_MAX_BVH_DEPTH) throw Unsupported("BVH deeper than RTMI_MAX_BVH_DEPTH");
+}
+
+rtmi_scene_desc LoweredScene::desc() const {
+    rtmi_scene_desc d{};
+    d.abi_version = RTMI_ABI_VERSION;
+    d.n_items = (uint32_t)items.size(); d.items = items.data();
+    d.n_prims = (uint32_t)prim_meta.size(); d.prim_a = prim_a.data(); d.prim_b = prim_b.data(); d.prim_meta = prim_meta.data();
+    d.n_nodes = (uint32_t)nodes.size(); d.nodes = nodes.data();
+    d.n_xforms = (uint32_t)xforms.size(); d.xforms = xforms.data();
+    d.n_materials = (uint32_t)materials.size(); d.materials = materials.data();
+    d.n_textures = (uint32_t)textures.size(); d.textures = textures.data();
+    d.n_perlin = (uint32_t)perlin.size(); d.perlin = perlin.data();
+    d.n_images = (uint32_t)images.size(); d.images = images.data();
+    d.image_data = image_data.data(); d.image_bytes = image_data.size();
+    d.max_bvh_depth = max_bvh_depth;
+    return d;
+}
+LoweredScene lower_scene(const Hittable &world) {
+    SceneBuilder b;
+    b.lower_world(world);
+    return std::move(b.out);
+}
+
+// ======================================================================================
+// Camera — src/camera.rs:21-67, plus render()/create_image on the device
+// ======================================================================================
+Camera::Camera(const Vec3 &look_from, const Vec3 &look_at, const Vec3 &view_up, double vertical_fov, double aspect,
+               double aperture, double focus_dist, double time0, double time1) {
+    const double theta = vertical_fov * kPi / 180.0;
+    const double half_height = focus_dist * std::tan(theta / 2.0);
+    const double half_width = aspect * half_height;
+    const Vec3 w = (look_from - look_at).normalize();
+    const Vec3 u = view_up.cross(w).normalize();
+    const Vec3 v = w.cross(u);
+    origin_ = look_from;
+    lower_left_corner_ = look_from - half_width * u - half_height * v - focus_dist * w;
+    horizontal_ = 2.0 * half_width * u;
+    vertical_ = 2.0 * half_height * v;
+    u_ = u; v_ = v;
+    time0_ = time0; time1_ = time1;
+    lens_radius_ = aperture / 2.0;
+}
+Ray Camera::get_ray(double s, double t) const {
+    Vec3 origin = origin_;
+    if (lens_radius_ != 0.0) {
+        const Vec3 rd = lens_radius_ * random_in_unit_disk();
+        origin = origin_ + (u_ * rd.x + v_ * rd.y);
+    }
+    const double time = time0_ + render_rng().gen() * (time1_ - time0_);
+    return Ray(origin, lower_left_corner_ + s * horizontal_ + t * vertical_ - origin, time);
+}
+rtmi_camera Camera::lower() const {
+    rtmi_camera c{};
+    const Vec3 *src[6] = {&origin_, &lower_left_corner_, &horizontal_, &vertical_, &u_, &v_};
+    float *dst[6] = {c.origin, c.lower_left_corner, c.horizontal, c.vertical, c.u, c.v};
+    for (int i = 0; i < 6; i++) { dst[i][0] = (float)src[i]->x; dst[i][1] = (float)src[i]->y; dst[i][2] = (float)src[i]->z; }
+    c.time0 = (float)time0_; c.time1 = (float)time1_; c.lens_radius = (float)lens_radius_;
+    return c;
+}
+
+Image Camera::render(const Hittable &world, uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt) const {
+    const LoweredScene ls = lower_scene(world);
+    const rtmi_scene_desc d = ls.desc();
+    rtmi_scene *scene = nullptr;
+    if (int rc = rtmi_scene_create(&d, opt.device, &scene))
+        throw std::runtime_error(std::string("rtmi_scene_create: ") + rtmi_last_error() + " (code " + std::to_string(rc) + ")");
+    rtmi_render_params p{};
+    p.nx = nx; p.ny = ny; p.ns = ns; p.max_depth = opt.max_depth; p.t_min = (float)opt.t_min; p.flags = opt.flags;
+    p.seed = opt.seed; p.tile_rank = 0; p.tile_world = 1; p.spp_chunks = opt.spp_chunks;
+    const rtmi_camera c = lower();
+    Image img;
+    img.nx = nx; img.ny = ny;
+    img.linear.resize((size_t)nx * ny * 3);
+    img.rgb8.resize((size_t)nx * ny * 3);
+    const int rc = rtmi_render(scene, &c, &p, img.linear.data(), img.rgb8.data(), &img.stats);
+    const std::string err = rc ? rtmi_last_error() : "";
+    rtmi_scene_destroy(scene);
+    if (rc) throw std::runtime_error("rtmi_render: " + err);
+    return img;
+}
+std::string Image::to_ppm() const {
+    std::string s;
+    s.resize(rtmi_ppm_p3(nx, ny, rgb8.data(), nullptr, 0));
+    s.resize(rtmi_ppm_p3(nx, ny, rgb8.data(), s.data(), s.size()));
+    return s;
+}
+std::string create_image(size_t ny, size_t nx, size_t ns, const Camera &cam, const Hittable &world, const RenderOptions &opt) {
+    return cam.render(world, (uint32_t)nx, (uint32_t)ny, (uint32_t)ns, opt).to_ppm();
+}
+
+} // namespace rt
