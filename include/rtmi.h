@@ -127,7 +127,8 @@ typedef struct {
     int32_t medium_material; /* MEDIUM: index of the Isotropic phase material (medium.rs:19-24) */
     float neg_inv_density;   /* MEDIUM: -(1/density) (medium.rs:40) */
     float root_min[3], root_max[3]; /* BVH: bbox of the root node (bvh.rs:60-64) */
-    int32_t pad[2];
+    float scale;             /* BVH: largest |coordinate| of the root box (fast-cull margins only) */
+    int32_t pad;
 } rtmi_item; /* 64 B */
 
 typedef struct {
@@ -162,6 +163,7 @@ typedef struct {
 } rtmi_camera;
 
 #define RTMI_FLAG_FAST_CULL 1u /* prune BVH subtrees behind the closest hit (same results) */
+#define RTMI_FLAG_PATH_SIG 2u  /* also accumulate the per-pixel path signature into path_sig */
 typedef struct {
     uint32_t nx, ny, ns; /* create_image(ny, nx, ns, ..) */
     uint32_t max_depth;  /* 50 (color.rs:9) */
@@ -171,7 +173,14 @@ typedef struct {
     uint32_t tile_rank, tile_world; /* this call renders tiles t with t % tile_world == tile_rank */
     uint32_t spp_chunks;            /* 0 = choose automatically */
     uint32_t pad;
+    uint64_t path_sig;              /* RTMI_FLAG_PATH_SIG: DEVICE address of rtmi_local_tiles()*64 uint64 (else 0) */
 } rtmi_render_params;
+
+/* Path signature (test/validation aid): for every hit query of every sample that finds a hit,
+ * mix(bits of the fp32 hit distance t, bounce index) is added (wrapping uint64) to the pixel's
+ * signature.  It pins the whole geometric path sequence, so two implementations can be compared
+ * bit-for-bit even on scenes whose radiance is identically zero.
+ *   mix(x,k): x ^= (k+1)*0x9E3779B9; x ^= x>>16; x *= 0x7FEB352D; x ^= x>>15; x *= 0x846CA68B; x ^= x>>16 */
 
 /* One framebuffer texel: mean linear radiance (before gamma) and the quantised
  * ir,ig,ib of tests/test.rs:71-78 packed as r | g<<8 | b<<16. */
@@ -211,7 +220,8 @@ int rtmi_render_device(rtmi_scene *scene, const rtmi_camera *cam, const rtmi_ren
  * out_linear_rgb: ny*nx*3 floats, row 0 = top row (reference j = ny-1); may be NULL
  * out_rgb8:       ny*nx*3 bytes, same order; may be NULL */
 int rtmi_render(rtmi_scene *scene, const rtmi_camera *cam, const rtmi_render_params *p, float *out_linear_rgb,
-                uint8_t *out_rgb8, rtmi_stats *stats);
+                uint8_t *out_rgb8, uint64_t *out_path_sig /* ny*nx, optional: sets RTMI_FLAG_PATH_SIG */,
+                rtmi_stats *stats);
 
 /* Host-side un-tiling of `tile_world` gathered local buffers (rank-major, each
  * rtmi_local_tiles(rank 0)*64 texels, i.e. padded to the largest rank) into raster order. */

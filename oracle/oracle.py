@@ -72,7 +72,7 @@ def _load(name):
         "orc_bvh": (vp, [vp, i, d, d]),
         "orc_camera": (vp, [d] * 15),
         "orc_camera_state": (None, [vp, vp]),
-        "orc_render": (i, [vp, vp, i, i, i, u64, i, i, d, i, i, vp, vp, vp]),
+        "orc_render": (i, [vp, vp, i, i, i, u64, i, i, d, i, i, vp, vp, vp, vp]),
         "orc_ppm_text": (C.c_size_t, [i, i, vp, vp, C.c_size_t]),
         "orc_hit": (i, [vp, vp, vp, d, d, d, i, u64, vp, vp]),
         "orc_bounding_box": (i, [vp, d, d, vp]),
@@ -213,16 +213,17 @@ class Oracle:
     # ---- the hot path ----
     def render(self, cam, world, nx, ny, ns, seed=42, flags=0, max_depth=50, t_min=0.001, rows=None):
         """create_image (tests/test.rs:55-85).  Returns dict(linear f32 [ny,nx,3],
-        rgb int32 [ny,nx,3], mean f64 [ny,nx,3]); row 0 is the top row."""
+        rgb int32 [ny,nx,3], mean f64 [ny,nx,3], sig u64 [ny,nx] path signatures); row 0 is the top row."""
         r0, r1 = (0, ny) if rows is None else rows
         lin = np.zeros((ny, nx, 3), np.float32)
         rgb = np.zeros((ny, nx, 3), np.int32)
         mean = np.zeros((ny, nx, 3), np.float64)
+        sig = np.zeros((ny, nx), np.uint64)
         rc = self.lib.orc_render(cam.h, world.h, nx, ny, ns, int(seed), flags, max_depth, t_min, r0, r1,
-                                 lin.ctypes.data, rgb.ctypes.data, mean.ctypes.data)
+                                 lin.ctypes.data, rgb.ctypes.data, mean.ctypes.data, sig.ctypes.data)
         if rc != 0:
             raise RuntimeError("orc_render failed")
-        return {"linear": lin, "rgb": rgb, "mean": mean}
+        return {"linear": lin, "rgb": rgb, "mean": mean, "sig": sig}
 
     def ppm_text(self, rgb):
         ny, nx = rgb.shape[:2]

@@ -768,10 +768,21 @@ static int bounding_box(const Hittable *h, double t0, double t1, AABBd *out) {
 /* ================================================================================== */
 typedef struct { const Hittable *world; int max_depth; REAL t_min; } RenderCtx;
 
+/* Path signature (validation aid, see include/rtmi.h): every hit query that finds a hit adds
+ * mix(bits of (float)t, bounce index) to the pixel's wrapping uint64 signature. */
+static uint64_t g_sig;
+static uint32_t sig_mix(uint32_t x, uint32_t k) {
+    x ^= (k + 1u) * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+static void sig_add(REAL t, int depth) { g_sig += (uint64_t)sig_mix(rtmi_f2u((float)t), (uint32_t)depth); }
+
 static V3 color(const RenderCtx *cx, const Ray *ray, int depth) {
     HitRecord rec;
     COUNT(C_QUERIES);
     if (hit(cx->world, ray, cx->t_min, R_MAX, &rec)) {
+        sig_add(rec.t, depth);
         V3 emitted = mat_emitted(rec.mat, rec.u, rec.v, rec.p);
         if (depth < cx->max_depth) {
             Ray scattered;
@@ -794,6 +805,7 @@ static V3 color_throughput(const RenderCtx *cx, Ray ray) {
         HitRecord rec;
         COUNT(C_QUERIES);
         if (!hit(cx->world, &ray, cx->t_min, R_MAX, &rec)) break;
+        sig_add(rec.t, depth);
         V3 emitted = mat_emitted(rec.mat, rec.u, rec.v, rec.p);
         L = v_add(L, v_mul(T, emitted));
         if (depth >= cx->max_depth) break;
@@ -1102,10 +1114,10 @@ static int32_t as_i32(double x) {
 /* Renders output rows [row_begin,row_end) (row 0 = top = reference j = ny-1) and, inside
  * them, samples [0,ns).  out_linear: ny*nx*3 float (mean radiance before gamma);
  * out_rgb: ny*nx*3 int32 (the ir/ig/ib the reference prints); out_mean: ny*nx*3 double.
- * Any output pointer may be NULL. */
+ * out_sig: ny*nx uint64 path signatures.  Any output pointer may be NULL. */
 ORC_API int orc_render(void *cam_, void *world_, int nx, int ny, int ns, uint64_t seed, int flags, int max_depth,
                        double t_min, int row_begin, int row_end, float *out_linear, int32_t *out_rgb,
-                       double *out_mean) {
+                       double *out_mean, uint64_t *out_sig) {
     const Camera *cam = (Camera *)cam_;
     RenderCtx cx;
     cx.world = (Hittable *)world_;
@@ -1118,6 +1130,7 @@ ORC_API int orc_render(void *cam_, void *world_, int nx, int ny, int ns, uint64_
         int j = ny - 1 - row; /* for j in (0..ny).rev() */
         for (int i = 0; i < nx; i++) {
             double col[3] = {0.0, 0.0, 0.0};
+            g_sig = 0;
             for (int s = 0; s < ns; s++) {
                 stream_init(&g_rng, seed, (uint32_t)s, (uint32_t)(j * nx + i), 0);
                 COUNT(C_SAMPLES);
@@ -1128,6 +1141,7 @@ ORC_API int orc_render(void *cam_, void *world_, int nx, int ny, int ns, uint64_
                 col[0] += (double)c.x; col[1] += (double)c.y; col[2] += (double)c.z;
             }
             size_t o = ((size_t)row * nx + i) * 3;
+            if (out_sig) out_sig[(size_t)row * nx + i] = g_sig;
             for (int ch = 0; ch < 3; ch++) {
                 double m = col[ch] / (double)ns;
                 if (out_mean) out_mean[o + ch] = m;

@@ -13,6 +13,7 @@ RTMI_ABI_VERSION = 1
 RTMI_MAX_BVH_DEPTH = 24
 RTMI_TILE = 8
 RTMI_FLAG_FAST_CULL = 1
+RTMI_FLAG_PATH_SIG = 2
 
 TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
@@ -56,7 +57,7 @@ class Item(C.Structure):
     _fields_ = [("kind", C.c_int32), ("first", C.c_int32), ("count", C.c_int32), ("flags", C.c_uint32),
                 ("xform_first", C.c_int32), ("xform_count", C.c_int32), ("medium_material", C.c_int32),
                 ("neg_inv_density", C.c_float), ("root_min", C.c_float * 3), ("root_max", C.c_float * 3),
-                ("pad", C.c_int32 * 2)]
+                ("scale", C.c_float), ("pad", C.c_int32)]
 
 
 class SceneDesc(C.Structure):
@@ -82,7 +83,8 @@ class Camera(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("ns", C.c_uint32), ("max_depth", C.c_uint32),
                 ("t_min", C.c_float), ("flags", C.c_uint32), ("seed", C.c_uint64),
-                ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("spp_chunks", C.c_uint32), ("pad", C.c_uint32)]
+                ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("spp_chunks", C.c_uint32), ("pad", C.c_uint32),
+                ("path_sig", C.c_uint64)]
 
 
 class Texel(C.Structure):
@@ -124,7 +126,7 @@ def load_rtmi():
     lib.rtmi_render_device.restype = C.c_int
     lib.rtmi_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     lib.rtmi_render.restype = C.c_int
-    lib.rtmi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    lib.rtmi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
     lib.rtmi_untile.restype = C.c_int
     lib.rtmi_untile.argtypes = [C.POINTER(RenderParams), vp, vp, vp]
     lib.rtmi_ppm_p3.restype = C.c_size_t
@@ -181,7 +183,7 @@ def load_host():
         "rth_lower": (vp, [vp]),
         "rth_lowered_desc": (i, [vp, C.POINTER(SceneDesc)]),
         "rth_upload": (i, [vp, i]),
-        "rth_render": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]),
+        "rth_render": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]),
         "rth_render_device": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]),
         "rth_camera_render": (i, [vp, vp, u32, u32, u32, u64, u32, i, vp, vp, C.POINTER(Stats)]),
         "rth_hit": (i, [vp, vp, vp, d, d, d, u64, vp, vp]),

@@ -73,6 +73,7 @@ struct DevParams {
     float t_min;
     uint32_t key0, key1;
     uint32_t tile_rank, tile_world, tiles_x, ntiles_local, nchunks;
+    unsigned long long *path_sig;
 };
 
 // ----------------------------------------------------------------------------------
@@ -286,44 +287,115 @@ __device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx,
     return h;
 }
 
-// BVHNode::hit — src/bvh.rs:70-89, iteratively, children visited left before right so
-// that folding leaf hits with "replace unless best.t < t" reproduces the pairwise
-// `l.t < r.t ? l : r` (tie -> right).  Every box and every leaf is tested against the
-// query's own (t_min, t_max), as in the reference.  stack: this lane's LDS column.
+// AABB::hit as above, additionally returning the entry distance max(t_min, near slabs).
+__device__ __forceinline__ bool aabb_hit_t(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                           const RayF &r, float t_min, float t_max, float &t_enter) {
+    float t0 = (mnx - r.o.x) * r.inv_d.x, t1 = (mxx - r.o.x) * r.inv_d.x;
+    bool neg = r.inv_d.x < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    bool fail = t_max <= t_min;
+    t0 = (mny - r.o.y) * r.inv_d.y; t1 = (mxy - r.o.y) * r.inv_d.y;
+    neg = r.inv_d.y < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    fail |= t_max <= t_min;
+    t0 = (mnz - r.o.z) * r.inv_d.z; t1 = (mxz - r.o.z) * r.inv_d.z;
+    neg = r.inv_d.z < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    fail |= t_max <= t_min;
+    t_enter = t_min;
+    return !fail;
+}
+
+// BVHNode::hit — src/bvh.rs:70-89, iteratively.
+//
+// EXACT (FAST = false): children visited left before right, so folding leaf hits with
+// "replace unless best.t < t" reproduces the pairwise `l.t < r.t ? l : r` (tie -> right).
+// Every box and every leaf is tested against the query's own (t_min, t_max), as in the
+// reference; a leaf child has no box test of its own (bvh.rs:72-73).
+//
+// FAST: the same result with fewer visits.  (1) the nearer child first; (2) a subtree is
+// skipped when its box is entered later than the best hit so far plus a generous margin
+// (no primitive inside can then beat or tie it); (3) a leaf child is skipped when the ray
+// misses its PADDED box (stored by the lowering).  The winner among equal t is the
+// primitive that is rightmost in the tree = the largest primitive index (leaves are stored
+// left to right), which is what the fold above yields.  Internal boxes are still tested
+// against (t_min, t_max) with the reference's own arithmetic, so they prune identically.
+// stack: this lane's LDS column (node refs); stack + 64*RTMI_MAX_BVH_DEPTH: entry distances.
 template <bool FAST>
-__device__ __forceinline__ bool bvh_query(const DevScene &sc, int root, const RayF &r, float time, float t_min,
-                                          float t_max, uint32_t *stack, float &t_out, int &pf_out) {
+__device__ __forceinline__ bool bvh_query(const DevScene &sc, int root, float scale, const RayF &r, float time,
+                                          float t_min, float t_max, uint32_t *stack, float &t_out, int &pf_out) {
     bool have = false;
-    float bt = 0.0f;
+    float bt = FAST ? RTMI_FLT_MAX : 0.0f;
     int bpf = 0;
     int sp = 0;
     int cur = root;
+    float *stack_t = reinterpret_cast<float *>(stack + 64 * RTMI_MAX_BVH_DEPTH);
+    // prune when t_enter > bt + |bt|/128 + scale/8192/|d|
+    const float m_abs = FAST ? scale * (1.0f / 8192.0f) * __builtin_sqrtf(r.inv_a) : 0.0f;
+    float limit = RTMI_FLT_MAX;
     for (;;) {
         if (cur >= 0) {
             const float4 *n = sc.nodes + (size_t)cur * 4;
             const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-            // a leaf child has no box test of its own in the reference (bvh.rs:72-73)
-            bool vl = left < 0 || aabb_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, t_min, t_max);
-            bool vr = right < 0 || aabb_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, t_min, t_max);
-            if (vl) {
-                if (vr) { stack[sp * 64] = (uint32_t)right; sp++; }
-                cur = left;
-                continue;
+            if (!FAST) {
+                bool vl = left < 0 || aabb_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, t_min, t_max);
+                bool vr = right < 0 || aabb_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, t_min, t_max);
+                if (right == left) vr = false; // BVHNode over one object: the same leaf twice, same result
+                if (vl) {
+                    if (vr) { stack[sp * 64] = (uint32_t)right; sp++; }
+                    cur = left;
+                    continue;
+                }
+                if (vr) { cur = right; continue; }
+            } else {
+                float tl, tr;
+                bool vl = aabb_hit_t(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, r, t_min, t_max, tl);
+                bool vr = aabb_hit_t(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, r, t_min, t_max, tr);
+                vl = vl && !(tl > limit);
+                vr = vr && !(tr > limit) && right != left;
+                if (vl && vr) {
+                    const bool lfirst = !(tr < tl);
+                    stack[sp * 64] = (uint32_t)(lfirst ? right : left);
+                    stack_t[sp * 64] = lfirst ? tr : tl;
+                    sp++;
+                    cur = lfirst ? left : right;
+                    continue;
+                }
+                if (vl) { cur = left; continue; }
+                if (vr) { cur = right; continue; }
             }
-            if (vr) { cur = right; continue; }
         } else {
             const int type = (int)(((uint32_t)cur >> 28) & 7u);
             const int idx = (int)((uint32_t)cur & 0x0fffffffu);
             float t;
             int pf;
             if (prim_test(sc, type, idx, r, time, t_min, t_max, t, pf)) {
-                if (!have || !(bt < t)) { bt = t; bpf = pf; have = true; }
+                if (!FAST) {
+                    if (!have || !(bt < t)) { bt = t; bpf = pf; have = true; }
+                } else {
+                    if (!have || t < bt || (t == bt && pf > bpf)) {
+                        bt = t; bpf = pf; have = true;
+                        limit = bt + (__builtin_fabsf(bt) * (1.0f / 128.0f) + m_abs);
+                    }
+                }
             }
         }
-        if (sp == 0) break;
-        sp--;
-        cur = (int)stack[sp * 64];
+        if (!FAST) {
+            if (sp == 0) break;
+            sp--;
+            cur = (int)stack[sp * 64];
+        } else {
+            bool got = false;
+            while (sp > 0) {
+                sp--;
+                if (!(stack_t[sp * 64] > limit)) { cur = (int)stack[sp * 64]; got = true; break; }
+            }
+            if (!got) break;
+        }
     }
     t_out = bt;
     pf_out = bpf;
@@ -340,7 +412,7 @@ __device__ __forceinline__ bool geom_query(const DevScene &sc, const rtmi_item &
         if (!aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1], I.root_max[2], r,
                       q_min, q_max))
             return false;
-        return bvh_query<FAST>(sc, I.first, r, time, q_min, q_max, stack, t_out, pf_out);
+        return bvh_query<FAST>(sc, I.first, I.scale, r, time, q_min, q_max, stack, t_out, pf_out);
     }
     // HittableList::hit — hittable.rs:37-47
     float cl = q_max;
@@ -462,13 +534,21 @@ __device__ __forceinline__ float schlick(float cosine, float ref_idx) { // mater
 // ----------------------------------------------------------------------------------
 // the render kernel
 // ----------------------------------------------------------------------------------
-template <bool FAST>
+__device__ __forceinline__ uint32_t sig_mix(uint32_t x, uint32_t k) {
+    x ^= (k + 1u) * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+template <bool FAST, bool SIG>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevScene sc, DevCamera cam, DevParams P,
                                                                            double *__restrict__ partial) {
-    __shared__ uint32_t lds_stack[WAVES_PER_BLOCK][RTMI_MAX_BVH_DEPTH][64];
+    // per wave: [0] node refs, [1] entry distances (FAST only); entry-major so lanes never bank-conflict
+    __shared__ uint32_t lds_stack[WAVES_PER_BLOCK][FAST ? 2 : 1][RTMI_MAX_BVH_DEPTH][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    uint32_t *stack = &lds_stack[wave][0][lane];
+    uint32_t *stack = &lds_stack[wave][0][0][lane];
+    unsigned long long sig = 0ull;
 
     const uint32_t item = blockIdx.x * WAVES_PER_BLOCK + wave; // (chunk, local tile)
     const uint32_t nitems = P.ntiles_local * P.nchunks;
@@ -558,6 +638,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
             }
         }
 
+        if (SIG && best_item >= 0) sig += (unsigned long long)sig_mix(__float_as_uint(closest), depth);
         if (best_item < 0) { // miss: black background (color.rs:21)
             acc0 += (double)L.x; acc1 += (double)L.y; acc2 += (double)L.z;
             s++; alive = false;
@@ -674,6 +755,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
     // partial[chunk][ltile][channel][lane]
     double *out = partial + ((size_t)item * 3) * 64 + lane;
     out[0] = acc0; out[64] = acc1; out[128] = acc2;
+    if (SIG && in_image) atomicAdd(P.path_sig + (size_t)ltile * 64 + lane, sig); // integer add: order-independent
 }
 
 // `col /= ns; sqrt; clamp; (255.99*c) as i32` — tests/test.rs:71-78, per local texel.
@@ -949,6 +1031,11 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     if (chunks > p->ns) chunks = p->ns;
     if (chunks == 0) chunks = 1;
     P.nchunks = chunks;
+    P.path_sig = reinterpret_cast<unsigned long long *>(p->path_sig);
+    if (p->flags & RTMI_FLAG_PATH_SIG) {
+        if (!p->path_sig) return fail(RTMI_ERR_INVALID, "RTMI_FLAG_PATH_SIG needs params.path_sig");
+        HIP_TRY(hipMemsetAsync(P.path_sig, 0, (size_t)P.ntiles_local * 64 * sizeof(unsigned long long), stream));
+    }
 
     const size_t need = (size_t)P.ntiles_local * chunks * 64 * 3 * sizeof(double);
     if (need > s->partial_bytes) {
@@ -969,12 +1056,12 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     const uint32_t nitems = P.ntiles_local * chunks;
     const uint32_t blocks = (nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (stats) HIP_TRY(hipEventRecord(s->ev[0], stream));
-    if (p->flags & RTMI_FLAG_FAST_CULL)
-        hipLaunchKernelGGL(rtmi_render_kernel<true>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, C, P,
-                           s->partial);
-    else
-        hipLaunchKernelGGL(rtmi_render_kernel<false>, dim3(blocks), dim3(64 * WAVES_PER_BLOCK), 0, stream, s->dev, C, P,
-                           s->partial);
+    const bool fast = (p->flags & RTMI_FLAG_FAST_CULL) != 0u, sigf = (p->flags & RTMI_FLAG_PATH_SIG) != 0u;
+    const dim3 grid(blocks), block(64 * WAVES_PER_BLOCK);
+    if (fast && sigf) hipLaunchKernelGGL((rtmi_render_kernel<true, true>), grid, block, 0, stream, s->dev, C, P, s->partial);
+    else if (fast) hipLaunchKernelGGL((rtmi_render_kernel<true, false>), grid, block, 0, stream, s->dev, C, P, s->partial);
+    else if (sigf) hipLaunchKernelGGL((rtmi_render_kernel<false, true>), grid, block, 0, stream, s->dev, C, P, s->partial);
+    else hipLaunchKernelGGL((rtmi_render_kernel<false, false>), grid, block, 0, stream, s->dev, C, P, s->partial);
     HIP_TRY(hipGetLastError());
     if (stats) HIP_TRY(hipEventRecord(s->ev[1], stream));
     const uint32_t ntex = P.ntiles_local * 64u;
@@ -1036,25 +1123,46 @@ extern "C" int rtmi_untile(const rtmi_render_params *p, const rtmi_texel *g, flo
     return RTMI_OK;
 }
 
-extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p, float *out_linear,
-                           uint8_t *out_rgb8, rtmi_stats *stats) {
+extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p_in, float *out_linear,
+                           uint8_t *out_rgb8, uint64_t *out_path_sig, rtmi_stats *stats) {
     if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
-    int rc = check_params(p);
+    int rc = check_params(p_in);
     if (rc) return rc;
-    if (p->tile_world != 1) return fail(RTMI_ERR_INVALID, "rtmi_render renders the whole image: tile_world must be 1");
+    if (p_in->tile_world != 1) return fail(RTMI_ERR_INVALID, "rtmi_render renders the whole image: tile_world must be 1");
     HIP_TRY(hipSetDevice(s->device));
-    const size_t ntex = (size_t)rtmi_local_tiles(p) * 64;
+    rtmi_render_params p = *p_in;
+    const size_t ntex = (size_t)rtmi_local_tiles(&p) * 64;
     if (ntex > s->texel_count) {
         if (s->texels) { HIP_TRY(hipFree(s->texels)); s->texels = nullptr; s->texel_count = 0; }
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->texels), ntex * sizeof(rtmi_texel)));
         s->texel_count = ntex;
     }
+    unsigned long long *d_sig = nullptr;
+    p.flags &= ~RTMI_FLAG_PATH_SIG;
+    p.path_sig = 0;
+    if (out_path_sig) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_sig), ntex * sizeof(unsigned long long)));
+        p.flags |= RTMI_FLAG_PATH_SIG;
+        p.path_sig = reinterpret_cast<uint64_t>(d_sig);
+    }
     rtmi_stats local{};
-    rc = rtmi_render_device(s, cam, p, s->texels, nullptr, stats ? stats : &local);
-    if (rc) return rc;
+    rc = rtmi_render_device(s, cam, &p, s->texels, nullptr, stats ? stats : &local);
+    if (rc) { if (d_sig) (void)hipFree(d_sig); return rc; }
     std::vector<rtmi_texel> host(ntex);
     HIP_TRY(hipMemcpy(host.data(), s->texels, ntex * sizeof(rtmi_texel), hipMemcpyDeviceToHost));
-    return rtmi_untile(p, host.data(), out_linear, out_rgb8);
+    if (out_path_sig) {
+        std::vector<unsigned long long> hs(ntex);
+        hipError_t e = hipMemcpy(hs.data(), d_sig, ntex * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipFree(d_sig);
+        if (e != hipSuccess) return fail(RTMI_ERR_DEVICE, "copying the path signature failed");
+        const uint32_t txn = tiles_x_of(&p);
+        for (uint32_t row = 0; row < p.ny; row++)
+            for (uint32_t px = 0; px < p.nx; px++) {
+                const uint32_t t = (row / RTMI_TILE) * txn + px / RTMI_TILE;
+                out_path_sig[(size_t)row * p.nx + px] = hs[(size_t)t * 64 + (row % RTMI_TILE) * RTMI_TILE + px % RTMI_TILE];
+            }
+    }
+    return rtmi_untile(&p, host.data(), out_linear, out_rgb8);
 }
 
 // P3 writer — tests/test.rs:59,79

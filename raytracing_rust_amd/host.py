@@ -107,18 +107,22 @@ class Scene:
         self.uploaded = True
         return self
 
-    def render(self, cam, nx, ny, ns, **kw):
-        """Blocking whole-image render -> dict(linear f32 [ny,nx,3], rgb8 u8 [ny,nx,3], stats)."""
+    def render(self, cam, nx, ny, ns, sig=False, **kw):
+        """Blocking whole-image render -> dict(linear f32 [ny,nx,3], rgb8 u8 [ny,nx,3], stats[, sig u64 [ny,nx]])."""
         if not self.uploaded:
             self.upload(kw.pop("device", 0))
         kw.pop("device", None)
         p = default_params(nx, ny, ns, **kw)
         lin = np.zeros((ny, nx, 3), np.float32)
         rgb = np.zeros((ny, nx, 3), np.uint8)
+        sg = np.zeros((ny, nx), np.uint64) if sig else None
         st = abi.Stats()
         self.host._check(self.host.lib.rth_render(self.h, cam.h, C.byref(p), lin.ctypes.data, rgb.ctypes.data,
-                                                   C.byref(st)))
-        return {"linear": lin, "rgb8": rgb, "stats": _stats(st)}
+                                                   sg.ctypes.data if sig else None, C.byref(st)))
+        out = {"linear": lin, "rgb8": rgb, "stats": _stats(st)}
+        if sig:
+            out["sig"] = sg
+        return out
 
     def local_tiles(self, params):
         return abi.load_rtmi().rtmi_local_tiles(C.byref(params))

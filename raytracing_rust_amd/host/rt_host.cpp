@@ -582,32 +582,44 @@ static void put_box(float mn[3], float mx[3], const AABB &b) {
     mx[0] = (float)b.max.x; mx[1] = (float)b.max.y; mx[2] = (float)b.max.z;
 }
 
-// BVHNode -> rtmi_bvh_node records in preorder; leaves appended left to right
-int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving) {
+// BVHNode -> rtmi_bvh_node records in preorder; leaves appended left to right (so the primitive
+// index is the in-order rank the fast-cull tie rule needs).  A node over one object
+// (bvh.rs:44-45: left and right are the same Rc) stores that leaf once, referenced twice.
+int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad) {
     if (depth > out.max_bvh_depth) out.max_bvh_depth = depth;
     const int32_t id = (int32_t)out.nodes.size();
     out.nodes.push_back(rtmi_bvh_node{});
-    int32_t child[2];
+    int32_t child[2] = {0, 0};
     const Hittable *ch[2] = {n.left_.get(), n.right_.get()};
     for (int c = 0; c < 2; c++) {
+        if (c == 1 && ch[1] == ch[0]) { // same object twice
+            child[1] = child[0];
+            rtmi_bvh_node &me = out.nodes[(size_t)id];
+            for (int k = 0; k < 3; k++) { me.rmin[k] = me.lmin[k]; me.rmax[k] = me.lmax[k]; }
+            break;
+        }
         bool flip = false;
         const Hittable *h = strip_flips(ch[c], flip);
         if (auto sub = dynamic_cast<const BVHNode *>(h)) {
             if (flip) throw Unsupported("FlipNormals around a BVHNode inside a BVH is not lowered");
-            child[c] = lower_bvh(*sub, depth + 1, force_moving);
+            child[c] = lower_bvh(*sub, depth + 1, force_moving, pad);
             rtmi_bvh_node &me = out.nodes[(size_t)id];
             put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, sub->bbox_);
         } else {
             const int prim = push_prim(*h, flip, force_moving);
             child[c] = RTMI_LEAF(out.prim_meta[(size_t)prim].type, prim);
-            // A leaf child has no box test in the reference (bvh.rs:72-73); the box is stored only
-            // for the optional fast-cull prefilter, so it must contain the primitive at EVERY ray
-            // time: exact for static primitives, unbounded for moving spheres.
+            // A leaf child has no box test in the reference (bvh.rs:72-73).  The box stored here is
+            // used only by the fast-cull prefilter, so it must contain every hit the primitive's own
+            // fp32 test can report, at EVERY ray time: the exact box padded by `pad` for static
+            // primitives, unbounded for moving spheres and for Rect (whose bounding_box ignores
+            // the plane, rect.rs:72-73).
             const double big = 3.40282346638528859811704183484516925e+38;
             AABB lb(Vec3(-big, -big, -big), Vec3(big, big, big));
-            if (!dynamic_cast<const MovingSphere *>(h)) {
-                auto b = h->bounding_box(0.0, 1.0);
-                if (b && !dynamic_cast<const Rect *>(h)) lb = *b; // Rect::bounding_box ignores the plane (rect.rs:72-73)
+            if (!dynamic_cast<const MovingSphere *>(h) && !dynamic_cast<const Rect *>(h)) {
+                if (auto b = h->bounding_box(0.0, 1.0)) {
+                    const Vec3 pd(pad, pad, pad);
+                    lb = AABB(b->min - pd, b->max + pd);
+                }
             }
             rtmi_bvh_node &me = out.nodes[(size_t)id];
             put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, lb);
@@ -654,7 +666,11 @@ void SceneBuilder::lower_item(const Hittable &top) {
     if (auto bvh = dynamic_cast<const BVHNode *>(h)) {
         it.kind = RTMI_ITEM_BVH;
         put_box(it.root_min, it.root_max, bvh->bbox_);
-        it.first = lower_bvh(*bvh, 1, contains_moving(bvh));
+        double scale = 0.0;
+        for (int k = 0; k < 3; k++) scale = std::fmax(scale, std::fmax(std::fabs(bvh->bbox_.min[k]), std::fabs(bvh->bbox_.max[k])));
+        if (!(scale < 1e30)) scale = 1e30;
+        it.scale = (float)scale;
+        it.first = lower_bvh(*bvh, 1, contains_moving(bvh), scale / 8192.0);
     } else if (auto list = dynamic_cast<const HittableList *>(h)) {
         it.kind = RTMI_ITEM_LIST;
         it.first = (int32_t)out.prim_meta.size();
@@ -756,7 +772,7 @@ Image Camera::render(const Hittable &world, uint32_t nx, uint32_t ny, uint32_t n
     img.nx = nx; img.ny = ny;
     img.linear.resize((size_t)nx * ny * 3);
     img.rgb8.resize((size_t)nx * ny * 3);
-    const int rc = rtmi_render(scene, &c, &p, img.linear.data(), img.rgb8.data(), &img.stats);
+    const int rc = rtmi_render(scene, &c, &p, img.linear.data(), img.rgb8.data(), nullptr, &img.stats);
     const std::string err = rc ? rtmi_last_error() : "";
     rtmi_scene_destroy(scene);
     if (rc) throw std::runtime_error("rtmi_render: " + err);

@@ -343,7 +343,7 @@ class SceneBuilder {
   private:
     void lower_item(const Hittable &h);
     int push_prim(const Hittable &h, bool flip, bool force_moving);
-    int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving);
+    int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad);
     std::map<const Texture *, int> tex_ids_;
     std::map<const Material *, int> mat_ids_;
 };

@@ -228,12 +228,12 @@ RTH_API int rth_upload(void *lowered, int device) {
     });
 }
 RTH_API int rth_render(void *lowered, void *cam, const rtmi_render_params *p, float *out_linear, uint8_t *out_rgb8,
-                       rtmi_stats *stats) {
+                       uint64_t *out_path_sig, rtmi_stats *stats) {
     return guard([&] {
         Obj *o = LOW(lowered);
         if (!o->dev) throw std::runtime_error("scene not uploaded: call rth_upload first");
         const rtmi_camera c = CAM(cam).lower();
-        if (rtmi_render(o->dev, &c, p, out_linear, out_rgb8, stats)) throw std::runtime_error(std::string("rtmi_render: ") + rtmi_last_error());
+        if (rtmi_render(o->dev, &c, p, out_linear, out_rgb8, out_path_sig, stats)) throw std::runtime_error(std::string("rtmi_render: ") + rtmi_last_error());
         return RTH_OK;
     });
 }
