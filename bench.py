@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1000, help="samples per pixel PER GPU (total spp = spp * gpus)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=16)
     ap.add_argument("--cpu-spp", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,7 +93,8 @@ def main():
     t_u = time.perf_counter()
     scene.upload(local_rank)
     t_upload = time.perf_counter() - t_u
-    params = rdist.rank_params(nx, ny, ns, rank, world, seed=42, flags=args.flags, spp_chunks=args.chunks)
+    params = rdist.rank_params(nx, ny, ns, rank, world, seed=42, flags=args.flags, spp_chunks=args.chunks,
+                               shade_threshold=args.shade_threshold)
     local = rdist.new_local_framebuffer(params, device)
     stream = torch.cuda.current_stream(device)
 

@@ -164,6 +164,9 @@ typedef struct {
 
 #define RTMI_FLAG_FAST_CULL 1u /* prune BVH subtrees behind the closest hit (same results) */
 #define RTMI_FLAG_PATH_SIG 2u  /* also accumulate the per-pixel path signature into path_sig */
+#define RTMI_FLAG_PROFILE 4u   /* diagnostics build: lane-activity counters into prof (64 uint64); slow */
+#define RTMI_FLAG_SYNC 8u      /* per-lane BVH traversal instead of the wave-cooperative one (exact mode always is) */
+#define RTMI_FLAG_ASYNC 16u    /* per-lane state-machine kernel (experimental, kept for comparison) */
 typedef struct {
     uint32_t nx, ny, ns; /* create_image(ny, nx, ns, ..) */
     uint32_t max_depth;  /* 50 (color.rs:9) */
@@ -172,8 +175,9 @@ typedef struct {
     uint64_t seed;
     uint32_t tile_rank, tile_world; /* this call renders tiles t with t % tile_world == tile_rank */
     uint32_t spp_chunks;            /* 0 = choose automatically */
-    uint32_t pad;
+    uint32_t shade_threshold;       /* two-phase kernel: lanes holding a hit before shading starts (0 = default 64) */
     uint64_t path_sig;              /* RTMI_FLAG_PATH_SIG: DEVICE address of rtmi_local_tiles()*64 uint64 (else 0) */
+    uint64_t prof;                  /* RTMI_FLAG_PROFILE: DEVICE address of 64 uint64 counters (else 0) */
 } rtmi_render_params;
 
 /* Path signature (test/validation aid): for every hit query of every sample that finds a hit,

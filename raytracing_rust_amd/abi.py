@@ -14,6 +14,9 @@ RTMI_MAX_BVH_DEPTH = 24
 RTMI_TILE = 8
 RTMI_FLAG_FAST_CULL = 1
 RTMI_FLAG_PATH_SIG = 2
+RTMI_FLAG_PROFILE = 4
+RTMI_FLAG_SYNC = 8
+RTMI_FLAG_ASYNC = 16
 
 TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
@@ -83,8 +86,8 @@ class Camera(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("ns", C.c_uint32), ("max_depth", C.c_uint32),
                 ("t_min", C.c_float), ("flags", C.c_uint32), ("seed", C.c_uint64),
-                ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("spp_chunks", C.c_uint32), ("pad", C.c_uint32),
-                ("path_sig", C.c_uint64)]
+                ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("spp_chunks", C.c_uint32), ("shade_threshold", C.c_uint32),
+                ("path_sig", C.c_uint64), ("prof", C.c_uint64)]
 
 
 class Texel(C.Structure):

@@ -12,7 +12,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_DIR = os.path.join(_PKG, "lib")
+LIB_DIR = os.environ.get("RTMI_LIB_DIR") or os.path.join(_PKG, "lib")
 INCLUDE = os.path.join(_ROOT, "include")
 
 RTMI_SRC = [os.path.join(_PKG, "csrc", "rtmi_device.hip")]

@@ -74,6 +74,11 @@ struct DevParams {
     uint32_t key0, key1;
     uint32_t tile_rank, tile_world, tiles_x, ntiles_local, nchunks;
     unsigned long long *path_sig;
+    unsigned long long *prof;
+    uint32_t stack_depth;
+    uint32_t shade_threshold;
+    uint32_t coop_cap;
+    unsigned int *status;
 };
 
 // ----------------------------------------------------------------------------------
@@ -287,6 +292,21 @@ __device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx,
     return h;
 }
 
+// ---- lane-activity profiling (PROF instantiation only; diagnostics, never on the timed path) -----
+// slot s: prof[2s] += active lanes, prof[2s+1] += 64 (one wave-iteration).  Accumulated in LDS,
+// flushed to global once per block.
+#define RTMI_PROF_SLOTS 32
+template <bool PROF>
+__device__ __forceinline__ void prof_tick(unsigned long long *prof_lds, int slot, bool active) {
+    if (PROF) {
+        const unsigned long long m = __ballot(active);
+        if (m != 0ull && (int)(__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63)) {
+            atomicAdd(&prof_lds[2 * slot], (unsigned long long)__popcll(m));
+            atomicAdd(&prof_lds[2 * slot + 1], 64ull);
+        }
+    }
+}
+
 // AABB::hit as above, additionally returning the entry distance max(t_min, near slabs).
 __device__ __forceinline__ bool aabb_hit_t(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                                            const RayF &r, float t_min, float t_max, float &t_enter) {
@@ -324,9 +344,10 @@ __device__ __forceinline__ bool aabb_hit_t(float mnx, float mny, float mnz, floa
 // left to right), which is what the fold above yields.  Internal boxes are still tested
 // against (t_min, t_max) with the reference's own arithmetic, so they prune identically.
 // stack: this lane's LDS column (node refs); stack + 64*RTMI_MAX_BVH_DEPTH: entry distances.
-template <bool FAST>
+template <bool FAST, bool PROF>
 __device__ __forceinline__ bool bvh_query(const DevScene &sc, int root, float scale, const RayF &r, float time,
-                                          float t_min, float t_max, uint32_t *stack, float &t_out, int &pf_out) {
+                                          float t_min, float t_max, uint32_t *stack, float &t_out, int &pf_out,
+                                          unsigned long long *prof, int slot) {
     bool have = false;
     float bt = FAST ? RTMI_FLT_MAX : 0.0f;
     int bpf = 0;
@@ -337,6 +358,9 @@ __device__ __forceinline__ bool bvh_query(const DevScene &sc, int root, float sc
     const float m_abs = FAST ? scale * (1.0f / 8192.0f) * __builtin_sqrtf(r.inv_a) : 0.0f;
     float limit = RTMI_FLT_MAX;
     for (;;) {
+        prof_tick<PROF>(prof, slot, true);          // lanes alive in this traversal iteration
+        prof_tick<PROF>(prof, 14, cur >= 0);        // ... of which at an internal node
+        prof_tick<PROF>(prof, 15, cur < 0);         // ... of which at a leaf
         if (cur >= 0) {
             const float4 *n = sc.nodes + (size_t)cur * 4;
             const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
@@ -403,16 +427,16 @@ __device__ __forceinline__ bool bvh_query(const DevScene &sc, int root, float sc
 }
 
 // geometry of one item against (q_min, q_max): HittableList scan or BVH
-template <bool FAST>
+template <bool FAST, bool PROF>
 __device__ __forceinline__ bool geom_query(const DevScene &sc, const rtmi_item &I, const RayF &r, float time,
                                            float q_min, float q_max, uint32_t *stack, float &t_out,
-                                           int &pf_out) {
+                                           int &pf_out, unsigned long long *prof, int slot) {
     if (I.kind == RTMI_ITEM_BVH) {
         // BVHNode::hit of the root: its own bbox first (bvh.rs:71)
         if (!aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1], I.root_max[2], r,
                       q_min, q_max))
             return false;
-        return bvh_query<FAST>(sc, I.first, I.scale, r, time, q_min, q_max, stack, t_out, pf_out);
+        return bvh_query<FAST, PROF>(sc, I.first, I.scale, r, time, q_min, q_max, stack, t_out, pf_out, prof, slot);
     }
     // HittableList::hit — hittable.rs:37-47
     float cl = q_max;
@@ -422,7 +446,209 @@ __device__ __forceinline__ bool geom_query(const DevScene &sc, const rtmi_item &
         const int type = sc.meta[idx].type;
         float t;
         int pf;
+        prof_tick<PROF>(prof, 13, true);            // list primitive tests
         if (prim_test(sc, type, idx, r, time, q_min, cl, t, pf)) { cl = t; any = true; pf_out = pf; }
+    }
+    t_out = cl;
+    return any;
+}
+
+// ----------------------------------------------------------------------------------
+// wave-cooperative BVH traversal (FAST semantics; RTMI_FLAG_COOP)
+//
+// Measured with per-lane traversal: only 5-13 % of the lanes are active per traversal iteration
+// — a few rays walk long while the others have left the tree or never entered it.  Here the 64
+// lanes of the wavefront are WORKERS on a wave-shared LIFO of (ray, node) entries in LDS:
+//   * every lane that owns a ray entering the tree publishes its ray context in LDS and pushes
+//     the root; then all 64 lanes, owners or not, pop entries and process them;
+//   * a worker that processed a node keeps the nearer surviving child itself (depth-first, so
+//     its ray context stays in registers) and pushes the farther one for anybody to take;
+//   * a leaf hit is folded into the ray's best hit with ONE LDS atomicMin on the 64-bit key
+//     (order-preserving bits of t, inverted primitive id): minimum t, ties -> the larger
+//     primitive index = the rightmost leaf, exactly the fold of BVHNode::hit (bvh.rs:75-81).
+//     The fold is order-independent, so the result does not depend on who processes what.
+// Pruning is the fast-cull rule (subtree entered later than the ray's best hit + margin);
+// internal boxes are tested against the query's own (t_min, t_max) with the reference's
+// arithmetic.  LIFO order makes workers take the deepest pending entries first, which bounds
+// the pool by 64 * (tree depth + 1) entries; the caller reports an overflow loudly.
+// ----------------------------------------------------------------------------------
+#define COOP_NONE 0xffffffffu
+#define COOP_SENTINEL 0xffffffffffffffffull
+__device__ __forceinline__ uint32_t f2sort(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float sort2f(uint32_t s) {
+    return __uint_as_float((s & 0x80000000u) ? (s & 0x7fffffffu) : ~s);
+}
+// node child reference (rtmi_bvh_node.left/right) -> 26-bit pool encoding
+__device__ __forceinline__ uint32_t coop_enc(int ref) {
+    if (ref >= 0) return (uint32_t)ref;
+    const uint32_t u = (uint32_t)ref;
+    return (1u << 25) | (((u >> 28) & 7u) << 22) | (u & 0x003fffffu);
+}
+
+// All 64 lanes must call this together.  LDS layout for this wave (uint32 words):
+//   pool [cap][2] | ctx [64][16] floats | best [64] uint64
+template <bool PROF>
+__device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, float scale, bool active, const RayF &R,
+                                               float time, float q_min, float q_max, uint32_t *wlds, int cap,
+                                               bool &have, float &t_out, int &pf_out, bool &overflow,
+                                               unsigned long long *prof, int slot) {
+    const int lane = threadIdx.x & 63;
+    volatile uint32_t *pool = wlds;
+    float4 *ctx = reinterpret_cast<float4 *>(wlds + 2 * cap);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(wlds + 2 * cap + 64 * 16);
+
+    const unsigned long long m_act = __ballot(active);
+    have = false;
+    if (m_act == 0ull) return; // wave-uniform: nobody enters this tree
+    // ---- publish ray contexts, push roots
+    best[lane] = COOP_SENTINEL;
+    if (active) {
+        const float m_abs = scale * (1.0f / 8192.0f) * __builtin_sqrtf(R.inv_a);
+        ctx[lane * 4 + 0] = make_float4(R.o.x, R.o.y, R.o.z, R.a);
+        ctx[lane * 4 + 1] = make_float4(R.d.x, R.d.y, R.d.z, R.inv_a);
+        ctx[lane * 4 + 2] = make_float4(R.inv_d.x, R.inv_d.y, R.inv_d.z, time);
+        ctx[lane * 4 + 3] = make_float4(q_min, q_max, m_abs, 0.0f);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u));
+        pool[2 * pos] = ((uint32_t)lane << 26) | (uint32_t)root;
+        pool[2 * pos + 1] = __float_as_uint(q_min); // entry distance of the root: conservative
+    }
+    int top = __popcll(m_act);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t cur = COOP_NONE; // 26-bit node/leaf encoding of the entry this worker holds
+    int ray = 0, cray = -1;
+    float tent = 0.0f;
+    RayF W;                   // context of ray `cray`
+    W.o = f3(0, 0, 0); W.d = f3(0, 0, 1); W.inv_d = f3(0, 0, 0); W.a = 1.0f; W.inv_a = 1.0f;
+    float wtime = 0.0f, wqmin = 0.0f, wqmax = 0.0f, wmabs = 0.0f;
+
+    for (;;) {
+        // ---- idle workers take the deepest pending entries
+        const bool needw = cur == COOP_NONE;
+        const unsigned long long m_need = __ballot(needw);
+        const int n_need = __popcll(m_need);
+        if (top == 0 && n_need == 64) break;
+        if (top > cap - 64) { overflow = true; break; }
+        const int take = n_need < top ? n_need : top;
+        if (needw) {
+            const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
+            if (r < take) {
+                const int idx = top - 1 - r;
+                const uint32_t e0 = pool[2 * idx];
+                tent = __uint_as_float(pool[2 * idx + 1]);
+                cur = e0 & 0x03ffffffu;
+                ray = (int)(e0 >> 26);
+            }
+        }
+        top -= take;
+        prof_tick<PROF>(prof, slot, cur != COOP_NONE);
+        bool push = false;
+        uint32_t push_ref = 0u;
+        float push_t = 0.0f;
+        if (cur != COOP_NONE) {
+            if (ray != cray) { // switch ray context
+                const float4 c0 = ctx[ray * 4 + 0], c1 = ctx[ray * 4 + 1], c2 = ctx[ray * 4 + 2], c3 = ctx[ray * 4 + 3];
+                W.o = f3(c0.x, c0.y, c0.z); W.a = c0.w;
+                W.d = f3(c1.x, c1.y, c1.z); W.inv_a = c1.w;
+                W.inv_d = f3(c2.x, c2.y, c2.z); wtime = c2.w;
+                wqmin = c3.x; wqmax = c3.y; wmabs = c3.z;
+                cray = ray;
+            }
+            // the ray's best hit so far -> pruning limit
+            const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(&best[ray]);
+            float limit = RTMI_FLT_MAX;
+            if (key != COOP_SENTINEL) {
+                const float bt = sort2f((uint32_t)(key >> 32));
+                limit = bt + (__builtin_fabsf(bt) * (1.0f / 128.0f) + wmabs);
+            }
+            if (tent > limit) {
+                cur = COOP_NONE;
+            } else if (!(cur & (1u << 25))) { // internal node
+                const float4 *n = sc.nodes + (size_t)cur * 4;
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                float tl, tr;
+                bool vl = aabb_hit_t(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, W, wqmin, wqmax, tl);
+                bool vr = aabb_hit_t(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, W, wqmin, wqmax, tr);
+                vl = vl && !(tl > limit);
+                vr = vr && !(tr > limit) && right != left;
+                if (vl && vr) {
+                    const bool lfirst = !(tr < tl);
+                    push = true;
+                    push_ref = coop_enc(lfirst ? right : left);
+                    push_t = lfirst ? tr : tl;
+                    cur = coop_enc(lfirst ? left : right);
+                    tent = lfirst ? tl : tr;
+                } else if (vl) { cur = coop_enc(left); tent = tl; }
+                else if (vr) { cur = coop_enc(right); tent = tr; }
+                else cur = COOP_NONE;
+            } else { // leaf
+                const int type = (int)((cur >> 22) & 7u);
+                const int idx = (int)(cur & 0x003fffffu);
+                float t;
+                int pf;
+                if (prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf)) {
+                    const unsigned long long k = ((unsigned long long)f2sort(t) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)pf);
+                    atomicMin(&best[ray], k);
+                }
+                cur = COOP_NONE;
+            }
+        }
+        // ---- publish the far children
+        const unsigned long long m_push = __ballot(push);
+        if (push) {
+            const int pos = top + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_push >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
+            pool[2 * pos] = ((uint32_t)ray << 26) | push_ref;
+            pool[2 * pos + 1] = __float_as_uint(push_t);
+        }
+        top += __popcll(m_push);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (active) {
+        const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(&best[lane]);
+        if (key != COOP_SENTINEL) {
+            have = true;
+            t_out = sort2f((uint32_t)(key >> 32));
+            pf_out = (int)(0x7fffffffu - (uint32_t)key);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// geometry of one item for the whole wavefront: every lane calls it; `active` lanes own a query
+template <bool PROF>
+__device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_item &I, bool active, const RayF &r,
+                                                float time, float q_min, float q_max, uint32_t *wlds, int cap,
+                                                float &t_out, int &pf_out, bool &overflow, unsigned long long *prof,
+                                                int slot) {
+    if (I.kind == RTMI_ITEM_BVH) { // wave-uniform branch
+        // BVHNode::hit of the root: its own bbox first (bvh.rs:71)
+        const bool enter = active && aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
+                                              I.root_max[2], r, q_min, q_max);
+        bool have = false;
+        coop_bvh_query<PROF>(sc, I.first, I.scale, enter, r, time, q_min, q_max, wlds, cap, have, t_out, pf_out, overflow,
+                             prof, slot);
+        return have;
+    }
+    // HittableList::hit — hittable.rs:37-47
+    float cl = q_max;
+    bool any = false;
+    if (active) {
+        for (int k = 0; k < I.count; k++) {
+            const int idx = I.first + k;
+            const int type = sc.meta[idx].type;
+            float t;
+            int pf;
+            prof_tick<PROF>(prof, 13, true);
+            if (prim_test(sc, type, idx, r, time, q_min, cl, t, pf)) { cl = t; any = true; pf_out = pf; }
+        }
     }
     t_out = cl;
     return any;
@@ -532,7 +758,7 @@ __device__ __forceinline__ float schlick(float cosine, float ref_idx) { // mater
 }
 
 // ----------------------------------------------------------------------------------
-// the render kernel
+// path pieces shared by the render kernels
 // ----------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t sig_mix(uint32_t x, uint32_t k) {
     x ^= (k + 1u) * 0x9E3779B9u;
@@ -540,222 +766,676 @@ __device__ __forceinline__ uint32_t sig_mix(uint32_t x, uint32_t k) {
     return x;
 }
 
-template <bool FAST, bool SIG>
+struct Path { // one camera path in flight (per lane)
+    F3 ro, rd;
+    float rtime;
+    F3 T, L;
+    uint32_t depth;
+};
+
+// next sample of this pixel: tests/test.rs:66-68 + Camera::get_ray (camera.rs:53-67)
+__device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevParams &P, Rng &g, uint32_t k0, uint32_t k1,
+                                              uint32_t s, uint32_t pixel, uint32_t px, uint32_t j, Path &pa) {
+    rng_init(g, s, pixel);
+    const float u = ((float)px + rng_uniform(g, k0, k1)) / (float)P.nx;
+    const float v = ((float)j + rng_uniform(g, k0, k1)) / (float)P.ny;
+    F3 origin = cam.origin;
+    if (cam.lens_radius != 0.0f) {
+        const F3 rdk = random_in_unit_disk(g, k0, k1) * cam.lens_radius;
+        const F3 offset = cam.u * rdk.x + cam.v * rdk.y;
+        origin = cam.origin + offset;
+    }
+    pa.rtime = cam.time0 + rng_uniform(g, k0, k1) * (cam.time1 - cam.time0);
+    pa.ro = origin;
+    pa.rd = cam.llc + cam.horizontal * u + cam.vertical * v - origin;
+    pa.T = f3(1, 1, 1);
+    pa.L = f3(0, 0, 0);
+    pa.depth = 0;
+}
+
+// ConstantMedium::hit after both boundary queries — medium.rs:33-53.  Returns true when the
+// medium scatters before the boundary exit / the closest hit so far; the draw happens only when
+// the clamped interval is non-empty, as in the reference.
+__device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, F3 world_d,
+                                              float neg_inv_density, Rng &g, uint32_t k0, uint32_t k1, float &t_out) {
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > closest) t2 = closest;
+    if (t1 < t2) {
+        const float dn = norm(world_d);
+        const float dist_inside = (t2 - t1) * dn;
+        const float hit_distance = neg_inv_density * rtmi_logf(rng_uniform(g, k0, k1));
+        if (hit_distance < dist_inside) {
+            t_out = t1 + hit_distance / dn;
+            return true;
+        }
+    }
+    return false;
+}
+
+// HitRecord of the closest hit (hittable.rs:9-16), built once, then
+// color(): emitted + attenuation * color(scattered) — color.rs:8-15, in throughput form.
+// Returns true when the path continues (pa holds the scattered ray), false when it ended.
+__device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth, Rng &g, uint32_t k0, uint32_t k1,
+                                          float closest, int best_item, int best_pf, bool best_medium, Path &pa) {
+    const rtmi_item I = sc.items[best_item];
+    F3 hp, hn;
+    float hu = 0.0f, hv = 0.0f;
+    int mat_idx;
+    if (best_medium) {
+        hp = pa.ro + pa.rd * closest;      // ray.pointing_at(t) — medium.rs:47
+        hn = f3(1.0f, 0.0f, 0.0f);         // medium.rs:48
+        mat_idx = I.medium_material;
+    } else {
+        F3 lo = pa.ro, ld = pa.rd;
+        if (I.xform_count > 0) xform_ray(sc.xforms, I.xform_first, I.xform_count, lo, ld);
+        const int idx = best_pf >> 3, face = best_pf & 7;
+        const rtmi_prim_meta M = sc.meta[idx];
+        const float4 A = sc.prim_a[idx];
+        mat_idx = M.material;
+        const bool needs_uv = (sc.mats[mat_idx].flags & RTMI_MATFLAG_NEEDS_UV) != 0u;
+        hp = lo + ld * closest; // ray.pointing_at(t)
+        if (M.type == RTMI_PRIM_SPHERE || M.type == RTMI_PRIM_MSPHERE) {
+            F3 c = f3(A.x, A.y, A.z);
+            if (M.type == RTMI_PRIM_MSPHERE) c = moving_center(A, sc.prim_b[idx], M.inv_dt, pa.rtime);
+            hn = vdiv(hp - c, A.w); // sphere.rs:50 — outward, never face-forwarded
+            if (needs_uv) sphere_uv(hn, hu, hv);
+        } else {
+            int plane;
+            float x0, y0, x1, y1;
+            if (M.type == RTMI_PRIM_RECT) {
+                plane = (int)((M.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
+                x0 = A.x; y0 = A.y; x1 = A.z; y1 = A.w;
+            } else { // cube face -> its rect (cube.rs:21-74)
+                const float4 B = sc.prim_b[idx];
+                const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
+                if (face < 2) { plane = 2; x0 = ax; y0 = ay; x1 = bx; y1 = by; }
+                else if (face < 4) { plane = 1; x0 = az; y0 = ax; x1 = bz; y1 = bx; }
+                else { plane = 0; x0 = ay; y0 = az; x1 = by; y1 = bz; }
+            }
+            hn = f3(plane == 0 ? 1.0f : 0.0f, plane == 1 ? 1.0f : 0.0f, plane == 2 ? 1.0f : 0.0f); // rect.rs:58-59
+            if (needs_uv) { // rect.rs:52-56
+                const float x = plane == 0 ? lo.y + closest * ld.y : (plane == 1 ? lo.z + closest * ld.z : lo.x + closest * ld.x);
+                const float y = plane == 0 ? lo.z + closest * ld.z : (plane == 1 ? lo.x + closest * ld.x : lo.y + closest * ld.y);
+                hu = (x - x0) / (x1 - x0);
+                hv = (y - y0) / (y1 - y0);
+            }
+        }
+        if (I.xform_count > 0) xform_hit(sc.xforms, I.xform_first, I.xform_count, hp, hn);
+        if (((M.flags ^ I.flags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
+    }
+
+    const rtmi_material M = sc.mats[mat_idx];
+    if (M.kind == RTMI_MAT_DIFFUSE_LIGHT) { // material.rs:148-150
+        const F3 e = tex_value(sc, M.tex, hu, hv, hp);
+        pa.L = pa.L + pa.T * e;
+    }
+    bool scattered = false;
+    const F3 rd = pa.rd;
+    F3 nd = rd, att = f3(1, 1, 1);
+    if (pa.depth < max_depth) {
+        if (M.kind == RTMI_MAT_LAMBERTIAN) { // material.rs:49-53 (contract: dir = normal + rand)
+            nd = hn + random_in_unit_sphere(g, k0, k1);
+            att = tex_value(sc, M.tex, hu, hv, hp);
+            scattered = true;
+        } else if (M.kind == RTMI_MAT_METAL) { // material.rs:75-87
+            F3 refl = reflect(normalize(rd), hn);
+            if (M.param > 0.0f) refl = refl + random_in_unit_sphere(g, k0, k1) * M.param;
+            if (dot(refl, hn) > 0.0f) {
+                nd = refl;
+                att = tex_value(sc, M.tex, hu, hv, hp);
+                scattered = true;
+            }
+        } else if (M.kind == RTMI_MAT_DIELECTRIC) { // material.rs:106-126
+            F3 outward;
+            float ni_over_nt, cosine;
+            const float ddn = dot(rd, hn);
+            if (ddn > 0.0f) {
+                cosine = M.param * ddn / norm(rd);
+                outward = -hn;
+                ni_over_nt = M.param;
+            } else {
+                cosine = -ddn / norm(rd);
+                outward = hn;
+                ni_over_nt = 1.0f / M.param;
+            }
+            F3 refr;
+            bool took_refraction = false;
+            if (refract(rd, outward, ni_over_nt, refr)) {
+                const float reflect_prob = schlick(cosine, M.param);
+                if (rng_uniform(g, k0, k1) >= reflect_prob) { nd = refr; took_refraction = true; }
+            }
+            if (!took_refraction) nd = reflect(rd, hn);
+            scattered = true;
+        } else if (M.kind == RTMI_MAT_ISOTROPIC) { // material.rs:165-168
+            nd = random_in_unit_sphere(g, k0, k1);
+            att = tex_value(sc, M.tex, hu, hv, hp);
+            scattered = true;
+        }
+    }
+    if (scattered) {
+        pa.T = pa.T * att;
+        pa.ro = hp;
+        pa.rd = nd;
+        pa.depth++;
+    }
+    return scattered;
+}
+
+// work item of a wavefront: (sample chunk, local tile) -> pixel of this lane
+struct LaneJob {
+    uint32_t item, ltile, px, j, pixel, s_begin, s_end;
+    bool in_image, wave_has_work;
+};
+__device__ __forceinline__ LaneJob lane_job(const DevParams &P, int wave, int lane) {
+    LaneJob J;
+    J.item = blockIdx.x * WAVES_PER_BLOCK + wave; // (chunk, local tile)
+    const uint32_t nitems = P.ntiles_local * P.nchunks;
+    J.wave_has_work = J.item < nitems;
+    const uint32_t chunk = J.item / P.ntiles_local;
+    J.ltile = J.item - chunk * P.ntiles_local;
+    const uint32_t tile = J.ltile * P.tile_world + P.tile_rank;
+    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    J.px = tx * RTMI_TILE + (lane & 7);
+    const uint32_t row = ty * RTMI_TILE + (lane >> 3);
+    J.in_image = J.px < P.nx && row < P.ny;
+    J.j = P.ny - 1u - row;          // `for j in (0..ny).rev()` — tests/test.rs:62
+    J.pixel = J.j * P.nx + J.px;    // stream id of this pixel
+    J.s_begin = (uint32_t)(((uint64_t)P.ns * chunk) / P.nchunks);
+    J.s_end = (uint32_t)(((uint64_t)P.ns * (chunk + 1)) / P.nchunks);
+    return J;
+}
+
+// ----------------------------------------------------------------------------------
+// render kernel, two-phase form (RTMI_FLAG_SYNC): the wavefront alternates between
+//   phase A  every lane that holds no unshaded hit traces: (next camera sample if its path ended)
+//            + world.hit(); a lane whose ray misses immediately starts its next sample and traces
+//            again, while lanes that already found a hit wait.  The phase ends when at least
+//            `P.shade_threshold` lanes hold a hit (or no lane can produce one any more).
+//   phase B  all lanes holding a hit build the hit record and run the material.
+// Shading (Perlin turbulence, rejection samplers, Philox refills, ...) is expensive and very
+// divergent; batching it until most lanes need it runs it at high lane utilisation, at the
+// price of a few partially filled tracing rounds.  Per-lane program order is unchanged, so
+// results do not depend on the threshold.
+// ----------------------------------------------------------------------------------
+template <bool FAST, bool SIG, bool PROF>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevScene sc, DevCamera cam, DevParams P,
                                                                            double *__restrict__ partial) {
+    __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
+    unsigned long long *prof = prof_lds;
+    if (PROF) {
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS) prof_lds[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
     // per wave: [0] node refs, [1] entry distances (FAST only); entry-major so lanes never bank-conflict
     __shared__ uint32_t lds_stack[WAVES_PER_BLOCK][FAST ? 2 : 1][RTMI_MAX_BVH_DEPTH][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     uint32_t *stack = &lds_stack[wave][0][0][lane];
     unsigned long long sig = 0ull;
-
-    const uint32_t item = blockIdx.x * WAVES_PER_BLOCK + wave; // (chunk, local tile)
-    const uint32_t nitems = P.ntiles_local * P.nchunks;
-    if (item >= nitems) return;
-    const uint32_t chunk = item / P.ntiles_local;
-    const uint32_t ltile = item - chunk * P.ntiles_local;
-    const uint32_t tile = ltile * P.tile_world + P.tile_rank;
-    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    const uint32_t px = tx * RTMI_TILE + (lane & 7), row = ty * RTMI_TILE + (lane >> 3);
-    const bool in_image = px < P.nx && row < P.ny;
-    const uint32_t j = P.ny - 1u - row;         // `for j in (0..ny).rev()` — tests/test.rs:62
-    const uint32_t pixel = j * P.nx + px;       // stream id of this pixel
-    const uint32_t s_begin = (uint32_t)(((uint64_t)P.ns * chunk) / P.nchunks);
-    const uint32_t s_end = (uint32_t)(((uint64_t)P.ns * (chunk + 1)) / P.nchunks);
+    const LaneJob J = lane_job(P, wave, lane);
+    if (!PROF && !J.wave_has_work) return;
     const uint32_t k0 = P.key0, k1 = P.key1;
+    const int threshold = (int)P.shade_threshold;
 
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0; // `col += color(..)` — tests/test.rs:69 (f64 like the reference)
-    uint32_t s = in_image ? s_begin : s_end;
-    bool alive = false;
+    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
+    bool alive = false, done = s >= J.s_end, have_hit = false;
     Rng g;
     rng_init(g, 0, 0);
-    F3 ro = f3(0, 0, 0), rd = f3(0, 0, 1);
-    float rtime = 0.0f;
-    F3 T = f3(1, 1, 1), L = f3(0, 0, 0);
-    uint32_t depth = 0;
+    Path pa;
+    pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
+    float closest = RTMI_FLT_MAX;
+    int best_item = -1, best_pf = 0;
+    bool best_medium = false;
 
     for (;;) {
-        if (!alive) {
-            if (s >= s_end) break;
-            // ---- next sample: tests/test.rs:66-68 + Camera::get_ray (camera.rs:53-67)
-            rng_init(g, s, pixel);
-            const float u = ((float)px + rng_uniform(g, k0, k1)) / (float)P.nx;
-            const float v = ((float)j + rng_uniform(g, k0, k1)) / (float)P.ny;
-            F3 origin = cam.origin;
-            if (cam.lens_radius != 0.0f) {
-                const F3 rdk = random_in_unit_disk(g, k0, k1) * cam.lens_radius;
-                const F3 offset = cam.u * rdk.x + cam.v * rdk.y;
-                origin = cam.origin + offset;
-            }
-            rtime = cam.time0 + rng_uniform(g, k0, k1) * (cam.time1 - cam.time0);
-            ro = origin;
-            rd = cam.llc + cam.horizontal * u + cam.vertical * v - origin;
-            T = f3(1, 1, 1);
-            L = f3(0, 0, 0);
-            depth = 0;
-            alive = true;
-        }
-
-        // ---- world.hit(ray, 0.001, f64::MAX): scan of the top-level list (hittable.rs:37-47)
-        RayF W;
-        W.o = ro; W.d = rd;
-        ray_derive(W);
-        float closest = RTMI_FLT_MAX;
-        int best_item = -1, best_pf = 0;
-        bool best_medium = false;
-        for (uint32_t it = 0; it < sc.n_items; it++) {
-            const rtmi_item I = sc.items[it];
-            RayF R = W;
-            if (I.xform_count > 0) {
-                if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
-            }
-            if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
-                float t;
-                int pf;
-                if (geom_query<FAST>(sc, I, R, rtime, P.t_min, closest, stack, t, pf)) {
-                    closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
+        // ================= phase A: trace until enough lanes hold a hit =================
+        for (;;) {
+            const bool need = !have_hit && !done;
+            if (__ballot(need) == 0ull) break;
+            prof_tick<PROF>(prof, 0, need);
+            if (need) {
+                if (!alive) {
+                    camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
+                    alive = true;
                 }
-            } else {
-                // ConstantMedium::hit — medium.rs:28-56
-                float t1, t2;
-                int pf;
-                if (geom_query<FAST>(sc, I, R, rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, stack, t1, pf)) {
-                    if (geom_query<FAST>(sc, I, R, rtime, t1 + 0.0001f, RTMI_FLT_MAX, stack, t2, pf)) {
-                        if (t1 < P.t_min) t1 = P.t_min;
-                        if (t2 > closest) t2 = closest;
-                        if (t1 < t2) {
-                            const float dn = norm(W.d);
-                            const float dist_inside = (t2 - t1) * dn;
-                            const float hit_distance = I.neg_inv_density * rtmi_logf(rng_uniform(g, k0, k1));
-                            if (hit_distance < dist_inside) {
-                                closest = t1 + hit_distance / dn;
-                                best_item = (int)it; best_medium = true;
+                // ---- world.hit(ray, 0.001, f64::MAX): scan of the top-level list (hittable.rs:37-47)
+                RayF W;
+                W.o = pa.ro; W.d = pa.rd;
+                ray_derive(W);
+                closest = RTMI_FLT_MAX;
+                best_item = -1; best_pf = 0; best_medium = false;
+                for (uint32_t it = 0; it < sc.n_items; it++) {
+                    const rtmi_item I = sc.items[it];
+                    RayF R = W;
+                    if (I.xform_count > 0) {
+                        if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
+                    }
+                    const int slot = 1 + (it < 11u ? (int)it : 11);
+                    if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
+                        float t;
+                        int pf;
+                        if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, P.t_min, closest, stack, t, pf, prof, slot)) {
+                            closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
+                        }
+                    } else {
+                        // ConstantMedium::hit — medium.rs:28-56
+                        float t1, t2, tm;
+                        int pf;
+                        if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, stack, t1, pf, prof, slot)) {
+                            if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, stack, t2, pf, prof, slot)) {
+                                if (medium_sample(t1, t2, P.t_min, closest, W.d, I.neg_inv_density, g, k0, k1, tm)) {
+                                    closest = tm; best_item = (int)it; best_medium = true;
+                                }
                             }
                         }
                     }
                 }
-            }
-        }
-
-        if (SIG && best_item >= 0) sig += (unsigned long long)sig_mix(__float_as_uint(closest), depth);
-        if (best_item < 0) { // miss: black background (color.rs:21)
-            acc0 += (double)L.x; acc1 += (double)L.y; acc2 += (double)L.z;
-            s++; alive = false;
-            continue;
-        }
-
-        // ---- HitRecord of the closest hit (hittable.rs:9-16), built once
-        const rtmi_item I = sc.items[best_item];
-        F3 hp, hn;
-        float hu = 0.0f, hv = 0.0f;
-        int mat_idx;
-        if (best_medium) {
-            hp = W.o + W.d * closest;          // ray.pointing_at(t) — medium.rs:47
-            hn = f3(1.0f, 0.0f, 0.0f);         // medium.rs:48
-            mat_idx = I.medium_material;
-        } else {
-            F3 lo = W.o, ld = W.d;
-            if (I.xform_count > 0) xform_ray(sc.xforms, I.xform_first, I.xform_count, lo, ld);
-            const int idx = best_pf >> 3, face = best_pf & 7;
-            const rtmi_prim_meta M = sc.meta[idx];
-            const float4 A = sc.prim_a[idx];
-            mat_idx = M.material;
-            const bool needs_uv = (sc.mats[mat_idx].flags & RTMI_MATFLAG_NEEDS_UV) != 0u;
-            hp = lo + ld * closest; // ray.pointing_at(t)
-            if (M.type == RTMI_PRIM_SPHERE || M.type == RTMI_PRIM_MSPHERE) {
-                F3 c = f3(A.x, A.y, A.z);
-                if (M.type == RTMI_PRIM_MSPHERE) c = moving_center(A, sc.prim_b[idx], M.inv_dt, rtime);
-                hn = vdiv(hp - c, A.w); // sphere.rs:50 — outward, never face-forwarded
-                if (needs_uv) sphere_uv(hn, hu, hv);
-            } else {
-                int plane;
-                float x0, y0, x1, y1;
-                if (M.type == RTMI_PRIM_RECT) {
-                    plane = (int)((M.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
-                    x0 = A.x; y0 = A.y; x1 = A.z; y1 = A.w;
-                } else { // cube face -> its rect (cube.rs:21-74)
-                    const float4 B = sc.prim_b[idx];
-                    const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
-                    if (face < 2) { plane = 2; x0 = ax; y0 = ay; x1 = bx; y1 = by; }
-                    else if (face < 4) { plane = 1; x0 = az; y0 = ax; x1 = bz; y1 = bx; }
-                    else { plane = 0; x0 = ay; y0 = az; x1 = by; y1 = bz; }
-                }
-                hn = f3(plane == 0 ? 1.0f : 0.0f, plane == 1 ? 1.0f : 0.0f, plane == 2 ? 1.0f : 0.0f); // rect.rs:58-59
-                if (needs_uv) { // rect.rs:52-56
-                    const float x = plane == 0 ? lo.y + closest * ld.y : (plane == 1 ? lo.z + closest * ld.z : lo.x + closest * ld.x);
-                    const float y = plane == 0 ? lo.z + closest * ld.z : (plane == 1 ? lo.x + closest * ld.x : lo.y + closest * ld.y);
-                    hu = (x - x0) / (x1 - x0);
-                    hv = (y - y0) / (y1 - y0);
+                if (best_item >= 0) {
+                    have_hit = true;
+                } else { // miss: black background (color.rs:21); the path ends, next sample
+                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                    s++; alive = false;
+                    done = s >= J.s_end;
                 }
             }
-            if (I.xform_count > 0) xform_hit(sc.xforms, I.xform_first, I.xform_count, hp, hn);
-            if (((M.flags ^ I.flags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
+            if (__popcll(__ballot(have_hit)) >= threshold) break;
         }
-
-        // ---- color(): emitted + attenuation * color(scattered) — color.rs:8-15
-        const rtmi_material M = sc.mats[mat_idx];
-        if (M.kind == RTMI_MAT_DIFFUSE_LIGHT) { // material.rs:148-150
-            const F3 e = tex_value(sc, M.tex, hu, hv, hp);
-            L = L + T * e;
-        }
-        bool scattered = false;
-        F3 nd = rd, att = f3(1, 1, 1);
-        if (depth < P.max_depth) {
-            if (M.kind == RTMI_MAT_LAMBERTIAN) { // material.rs:49-53 (contract: dir = normal + rand)
-                nd = hn + random_in_unit_sphere(g, k0, k1);
-                att = tex_value(sc, M.tex, hu, hv, hp);
-                scattered = true;
-            } else if (M.kind == RTMI_MAT_METAL) { // material.rs:75-87
-                F3 refl = reflect(normalize(rd), hn);
-                if (M.param > 0.0f) refl = refl + random_in_unit_sphere(g, k0, k1) * M.param;
-                if (dot(refl, hn) > 0.0f) {
-                    nd = refl;
-                    att = tex_value(sc, M.tex, hu, hv, hp);
-                    scattered = true;
-                }
-            } else if (M.kind == RTMI_MAT_DIELECTRIC) { // material.rs:106-126
-                F3 outward;
-                float ni_over_nt, cosine;
-                const float ddn = dot(rd, hn);
-                if (ddn > 0.0f) {
-                    cosine = M.param * ddn / norm(rd);
-                    outward = -hn;
-                    ni_over_nt = M.param;
-                } else {
-                    cosine = -ddn / norm(rd);
-                    outward = hn;
-                    ni_over_nt = 1.0f / M.param;
-                }
-                F3 refr;
-                bool took_refraction = false;
-                if (refract(rd, outward, ni_over_nt, refr)) {
-                    const float reflect_prob = schlick(cosine, M.param);
-                    if (rng_uniform(g, k0, k1) >= reflect_prob) { nd = refr; took_refraction = true; }
-                }
-                if (!took_refraction) nd = reflect(rd, hn);
-                scattered = true;
-            } else if (M.kind == RTMI_MAT_ISOTROPIC) { // material.rs:165-168
-                nd = random_in_unit_sphere(g, k0, k1);
-                att = tex_value(sc, M.tex, hu, hv, hp);
-                scattered = true;
+        // ================= phase B: shade every lane that holds a hit =================
+        if (__ballot(have_hit) == 0ull) break; // nobody holds a hit and nobody can trace: all done
+        prof_tick<PROF>(prof, 16, have_hit);
+        if (have_hit) {
+            have_hit = false;
+            if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+            if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+                // absorbed, emitter or depth limit: the path ends
+                acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                s++; alive = false;
+                done = s >= J.s_end;
             }
-        }
-        if (scattered) {
-            T = T * att;
-            ro = hp;
-            rd = nd;
-            depth++;
-        } else {
-            acc0 += (double)L.x; acc1 += (double)L.y; acc2 += (double)L.z;
-            s++; alive = false;
         }
     }
 
+    if (PROF) {
+        __syncthreads();
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
+        if (!J.wave_has_work) return;
+    }
     // partial[chunk][ltile][channel][lane]
-    double *out = partial + ((size_t)item * 3) * 64 + lane;
+    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
     out[0] = acc0; out[64] = acc1; out[128] = acc2;
-    if (SIG && in_image) atomicAdd(P.path_sig + (size_t)ltile * 64 + lane, sig); // integer add: order-independent
+    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig); // integer add: order-independent
+}
+
+// ----------------------------------------------------------------------------------
+// render kernel, two-phase form with wave-cooperative BVH traversal (default).
+// Same schedule as rtmi_render_kernel; the item scan of phase A is executed by ALL lanes (lanes
+// without a pending query are workers for the others' BVH traversals).
+// ----------------------------------------------------------------------------------
+template <bool SIG, bool PROF>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_coop(DevScene sc, DevCamera cam, DevParams P,
+                                                                         double *__restrict__ partial) {
+    __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
+    unsigned long long *prof = prof_lds;
+    if (PROF) {
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS) prof_lds[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; // per wave: pool | ctx | best
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cap = (int)P.coop_cap;
+    uint32_t *wlds = lds_dyn + (size_t)wave * (2u * cap + 64u * 16u + 128u);
+    unsigned long long sig = 0ull;
+    const LaneJob J = lane_job(P, wave, lane);
+    if (!PROF && !J.wave_has_work) return;
+    const uint32_t k0 = P.key0, k1 = P.key1;
+    const int threshold = (int)P.shade_threshold;
+
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
+    bool alive = false, done = s >= J.s_end, have_hit = false, overflow = false;
+    Rng g;
+    rng_init(g, 0, 0);
+    Path pa;
+    pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
+    float closest = RTMI_FLT_MAX;
+    int best_item = -1, best_pf = 0;
+    bool best_medium = false;
+
+    for (;;) {
+        // ================= phase A =================
+        for (;;) {
+            const bool need = !have_hit && !done;
+            if (__ballot(need) == 0ull) break;
+            prof_tick<PROF>(prof, 0, need);
+            if (need && !alive) {
+                camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
+                alive = true;
+            }
+            RayF W;
+            W.o = pa.ro; W.d = pa.rd;
+            ray_derive(W);
+            if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
+            for (uint32_t it = 0; it < sc.n_items; it++) { // executed by all 64 lanes
+                const rtmi_item I = sc.items[it];
+                RayF R = W;
+                if (I.xform_count > 0) {
+                    if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
+                }
+                const int slot = 1 + (it < 11u ? (int)it : 11);
+                if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
+                    float t;
+                    int pf;
+                    if (geom_query_coop<PROF>(sc, I, need, R, pa.rtime, P.t_min, closest, wlds, cap, t, pf, overflow, prof, slot)) {
+                        closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
+                    }
+                } else {
+                    // ConstantMedium::hit — medium.rs:28-56
+                    float t1 = 0.0f, t2 = 0.0f, tm;
+                    int pf;
+                    const bool h1 = geom_query_coop<PROF>(sc, I, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, wlds, cap, t1, pf, overflow, prof, slot);
+                    const bool h2 = geom_query_coop<PROF>(sc, I, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, wlds, cap, t2, pf, overflow, prof, slot);
+                    if (need && h1 && h2) {
+                        if (medium_sample(t1, t2, P.t_min, closest, W.d, I.neg_inv_density, g, k0, k1, tm)) {
+                            closest = tm; best_item = (int)it; best_medium = true;
+                        }
+                    }
+                }
+            }
+            if (need) {
+                if (best_item >= 0) {
+                    have_hit = true;
+                } else { // miss: black background (color.rs:21)
+                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                    s++; alive = false;
+                    done = s >= J.s_end;
+                }
+            }
+            if (__popcll(__ballot(have_hit)) >= threshold) break;
+        }
+        // ================= phase B =================
+        if (__ballot(have_hit) == 0ull) break;
+        prof_tick<PROF>(prof, 16, have_hit);
+        if (have_hit) {
+            have_hit = false;
+            if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+            if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+                acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                s++; alive = false;
+                done = s >= J.s_end;
+            }
+        }
+    }
+    if (__ballot(overflow) != 0ull && lane == 0) atomicAdd(P.status, 1u); // reported loudly by the host
+
+    if (PROF) {
+        __syncthreads();
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
+        if (!J.wave_has_work) return;
+    }
+    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
+    out[0] = acc0; out[64] = acc1; out[128] = acc2;
+    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig);
+}
+
+// ----------------------------------------------------------------------------------
+// render kernel, asynchronous form (default).
+//
+// Measured on the synchronous kernel: inside BVH traversal only 4-10 % of the lanes are active
+// per iteration (a few lanes walk long while the rest have already left the tree), because the
+// whole wavefront waits at every item and at every bounce.  Here every lane is its own state
+// machine over the SAME per-lane program order (items in list order, media draws in order, so
+// results are bit-identical): a lane that finished its hit query goes on to shade, to its next
+// bounce and to its next sample while others still traverse.  Each loop iteration the wavefront
+// VOTES (ballots) for the state most lanes are in and executes only that body, which lets lanes
+// that drifted apart re-converge; lanes in other states wait one round.
+//   ST_ITEM : commit the finished item into `closest` (incl. ConstantMedium logic), then enter
+//             following items; single-primitive items are tested right here
+//   ST_NODE : one BVH node step        ST_PRIM : one primitive (BVH leaf or nested-list member)
+//   ST_SHADE: hit record + material    ST_NEW  : next camera sample      ST_DONE
+// ----------------------------------------------------------------------------------
+enum { ST_ITEM = 0, ST_NODE = 1, ST_PRIM = 2, ST_SHADE = 3, ST_NEW = 4, ST_DONE = 5 };
+
+template <bool FAST, bool SIG, bool PROF>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevScene sc, DevCamera cam, DevParams P,
+                                                                          double *__restrict__ partial) {
+    __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
+    unsigned long long *prof = prof_lds;
+    if (PROF) {
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS) prof_lds[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; // [wave][2][stack_depth][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t SD = P.stack_depth;
+    uint32_t *stack = lds_dyn + (size_t)wave * 2u * SD * 64u + lane;
+    float *stack_t = reinterpret_cast<float *>(stack + SD * 64u);
+    unsigned long long sig = 0ull;
+    const LaneJob J = lane_job(P, wave, lane);
+    if (!PROF && !J.wave_has_work) return;
+    const uint32_t k0 = P.key0, k1 = P.key1;
+    const int n_items = (int)sc.n_items;
+
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
+    Rng g;
+    rng_init(g, 0, 0);
+    Path pa;
+    pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
+
+    // hit-query state
+    RayF W;             // world-frame ray of the current query
+    W.o = pa.ro; W.d = pa.rd; W.inv_d = f3(0, 0, 0); W.a = 1.0f; W.inv_a = 1.0f;
+    RayF R = W;         // ray in the frame of the current item
+    int it = 0, ph = 0; // item index, ConstantMedium phase (0: first boundary query, 1: second)
+    bool pending = false;           // item `it` has finished with (have, bt, bpf) and must be committed
+    float closest = RTMI_FLT_MAX, t1 = 0.0f;
+    int best_item = -1, best_pf = 0;
+    bool best_medium = false;
+    uint32_t iflags = 0u;
+    float q_min = 0.0f, q_max = 0.0f;
+    // traversal / list state of the current item
+    int cur = 0, sp = 0, pend = 0;  // node-or-leaf ref | list cursor, stack pointer, list end
+    bool have = false, is_list = false;
+    float bt = 0.0f, limit = RTMI_FLT_MAX, m_abs = 0.0f;
+    int bpf = 0;
+    int st = ST_NEW;
+
+    for (;;) {
+        // ---- vote
+        const unsigned long long mI = __ballot(st == ST_ITEM), mN = __ballot(st == ST_NODE), mP = __ballot(st == ST_PRIM),
+                                 mS = __ballot(st == ST_SHADE), mC = __ballot(st == ST_NEW);
+        const int nI = __popcll(mI), nN = __popcll(mN), nP = __popcll(mP), nS = __popcll(mS), nC = __popcll(mC);
+        if ((nI | nN | nP | nS | nC) == 0) break; // every lane is ST_DONE
+        int run = ST_ITEM, best_n = nI;
+        if (nN > best_n) { run = ST_NODE; best_n = nN; }
+        if (nP > best_n) { run = ST_PRIM; best_n = nP; }
+        if (nS > best_n) { run = ST_SHADE; best_n = nS; }
+        if (nC > best_n) { run = ST_NEW; best_n = nC; }
+        prof_tick<PROF>(prof, 20 + run, st == run);
+
+        if (run == ST_NODE) {
+            if (st == ST_NODE) {
+                const float4 *n = sc.nodes + (size_t)cur * 4;
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                int next = 0;
+                bool got = false;
+                if (!FAST) {
+                    bool vl = left < 0 || aabb_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, R, q_min, q_max);
+                    bool vr = right < 0 || aabb_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, R, q_min, q_max);
+                    if (right == left) vr = false;
+                    if (vl) {
+                        if (vr) { stack[sp * 64] = (uint32_t)right; sp++; }
+                        next = left; got = true;
+                    } else if (vr) { next = right; got = true; }
+                    if (!got && sp > 0) { sp--; next = (int)stack[sp * 64]; got = true; }
+                } else {
+                    float tl, tr;
+                    bool vl = aabb_hit_t(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, R, q_min, q_max, tl);
+                    bool vr = aabb_hit_t(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, R, q_min, q_max, tr);
+                    vl = vl && !(tl > limit);
+                    vr = vr && !(tr > limit) && right != left;
+                    if (vl && vr) {
+                        const bool lfirst = !(tr < tl);
+                        stack[sp * 64] = (uint32_t)(lfirst ? right : left);
+                        stack_t[sp * 64] = lfirst ? tr : tl;
+                        sp++;
+                        next = lfirst ? left : right; got = true;
+                    } else if (vl) { next = left; got = true; }
+                    else if (vr) { next = right; got = true; }
+                    while (!got && sp > 0) {
+                        sp--;
+                        if (!(stack_t[sp * 64] > limit)) { next = (int)stack[sp * 64]; got = true; }
+                    }
+                }
+                if (got) { cur = next; st = next >= 0 ? ST_NODE : ST_PRIM; }
+                else { pending = true; st = ST_ITEM; }
+            }
+        } else if (run == ST_PRIM) {
+            if (st == ST_PRIM) {
+                float t;
+                int pf;
+                if (is_list) { // HittableList::hit — hittable.rs:37-47 (nested list of primitives)
+                    const int type = sc.meta[cur].type;
+                    if (prim_test(sc, type, cur, R, pa.rtime, q_min, bt, t, pf)) { bt = t; bpf = pf; have = true; }
+                    cur++;
+                    if (cur >= pend) { pending = true; st = ST_ITEM; }
+                } else {       // BVH leaf
+                    const int type = (int)(((uint32_t)cur >> 28) & 7u);
+                    const int idx = (int)((uint32_t)cur & 0x0fffffffu);
+                    if (prim_test(sc, type, idx, R, pa.rtime, q_min, q_max, t, pf)) {
+                        if (!FAST) {
+                            if (!have || !(bt < t)) { bt = t; bpf = pf; have = true; }
+                        } else if (!have || t < bt || (t == bt && pf > bpf)) {
+                            bt = t; bpf = pf; have = true;
+                            limit = bt + (__builtin_fabsf(bt) * (1.0f / 128.0f) + m_abs);
+                        }
+                    }
+                    bool got = false;
+                    int next = 0;
+                    if (!FAST) {
+                        if (sp > 0) { sp--; next = (int)stack[sp * 64]; got = true; }
+                    } else {
+                        while (!got && sp > 0) {
+                            sp--;
+                            if (!(stack_t[sp * 64] > limit)) { next = (int)stack[sp * 64]; got = true; }
+                        }
+                    }
+                    if (got) { cur = next; st = next >= 0 ? ST_NODE : ST_PRIM; }
+                    else { pending = true; st = ST_ITEM; }
+                }
+            }
+        } else if (run == ST_ITEM) {
+            if (st == ST_ITEM) {
+                for (;;) {
+                    // ---- commit the finished item (hittable.rs:40-45; medium.rs:30-53)
+                    if (pending) {
+                        pending = false;
+                        if (!(iflags & RTMI_ITEMFLAG_MEDIUM)) {
+                            if (have) { closest = bt; best_item = it; best_pf = bpf; best_medium = false; }
+                            it++;
+                        } else if (ph == 0) {
+                            if (have) { t1 = bt; ph = 1; } else { it++; }
+                        } else {
+                            if (have) {
+                                float tm;
+                                if (medium_sample(t1, bt, P.t_min, closest, W.d, sc.items[it].neg_inv_density, g, k0, k1, tm)) {
+                                    closest = tm; best_item = it; best_medium = true;
+                                }
+                            }
+                            ph = 0;
+                            it++;
+                        }
+                    }
+                    // ---- end of the list: world.hit() is complete (color.rs:7)
+                    if (it >= n_items) {
+                        if (best_item >= 0) { st = ST_SHADE; }
+                        else { // miss: black background (color.rs:21)
+                            acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                            s++; st = ST_NEW;
+                        }
+                        break;
+                    }
+                    // ---- enter item `it`
+                    const rtmi_item I = sc.items[it];
+                    iflags = I.flags;
+                    R = W;
+                    if (I.xform_count > 0) {
+                        if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
+                    }
+                    if (iflags & RTMI_ITEMFLAG_MEDIUM) {
+                        q_min = ph == 0 ? -RTMI_FLT_MAX : t1 + 0.0001f;
+                        q_max = RTMI_FLT_MAX;
+                    } else {
+                        q_min = P.t_min;
+                        q_max = closest;
+                    }
+                    have = false;
+                    if (I.kind == RTMI_ITEM_BVH) {
+                        // BVHNode::hit of the root: its own bbox first (bvh.rs:71)
+                        if (!aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
+                                      I.root_max[2], R, q_min, q_max)) {
+                            pending = true;
+                            continue;
+                        }
+                        cur = I.first; sp = 0; is_list = false;
+                        bt = FAST ? RTMI_FLT_MAX : 0.0f; bpf = 0; limit = RTMI_FLT_MAX;
+                        m_abs = FAST ? I.scale * (1.0f / 8192.0f) * __builtin_sqrtf(R.inv_a) : 0.0f;
+                        st = ST_NODE;
+                        break;
+                    }
+                    if (I.count == 1) { // a single primitive: test it here
+                        float t;
+                        int pf;
+                        const int type = sc.meta[I.first].type;
+                        if (prim_test(sc, type, I.first, R, pa.rtime, q_min, q_max, t, pf)) { bt = t; bpf = pf; have = true; }
+                        pending = true;
+                        continue;
+                    }
+                    if (I.count <= 0) { pending = true; continue; }
+                    cur = I.first; pend = I.first + I.count; is_list = true; bt = q_max; bpf = 0;
+                    st = ST_PRIM;
+                    break;
+                }
+            }
+        } else if (run == ST_SHADE) {
+            if (st == ST_SHADE) {
+                if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+                if (shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+                    W.o = pa.ro; W.d = pa.rd;
+                    ray_derive(W);
+                    it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;
+                    st = ST_ITEM;
+                } else {
+                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                    s++; st = ST_NEW;
+                }
+            }
+        } else { // ST_NEW
+            if (st == ST_NEW) {
+                if (s >= J.s_end) { st = ST_DONE; }
+                else {
+                    camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
+                    W.o = pa.ro; W.d = pa.rd;
+                    ray_derive(W);
+                    it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;
+                    st = ST_ITEM;
+                }
+            }
+        }
+    }
+
+    if (PROF) {
+        __syncthreads();
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
+        if (!J.wave_has_work) return;
+    }
+    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
+    out[0] = acc0; out[64] = acc1; out[128] = acc2;
+    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig);
 }
 
 // `col /= ns; sqrt; clamp; (255.99*c) as i32` — tests/test.rs:71-78, per local texel.
@@ -833,6 +1513,7 @@ struct rtmi_scene {
     rtmi_scene_desc meta{}; // counts only (pointers nulled)
     double *partial = nullptr;
     size_t partial_bytes = 0;
+    unsigned int *status = nullptr; // device word: cooperative-traversal pool overflows (must stay 0)
     rtmi_texel *texels = nullptr; // scratch for the blocking host API
     size_t texel_count = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -963,6 +1644,11 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     }
     s->dev.nodes = nodes4;
     s->dev.n_items = d->n_items;
+    if (hipMalloc(reinterpret_cast<void **>(&s->status), sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(s->status, 0, sizeof(unsigned int)) != hipSuccess) {
+        rtmi_scene_destroy(s);
+        return fail(RTMI_ERR_DEVICE, "allocating the status word failed");
+    }
     for (int i = 0; i < 3; i++)
         if (hipEventCreate(&s->ev[i]) != hipSuccess) {
             rtmi_scene_destroy(s);
@@ -978,6 +1664,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->partial) (void)hipFree(s->partial);
     if (s->texels) (void)hipFree(s->texels);
+    if (s->status) (void)hipFree(s->status);
     for (int i = 0; i < 3; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
     delete s;
@@ -1058,10 +1745,51 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     if (stats) HIP_TRY(hipEventRecord(s->ev[0], stream));
     const bool fast = (p->flags & RTMI_FLAG_FAST_CULL) != 0u, sigf = (p->flags & RTMI_FLAG_PATH_SIG) != 0u;
     const dim3 grid(blocks), block(64 * WAVES_PER_BLOCK);
-    if (fast && sigf) hipLaunchKernelGGL((rtmi_render_kernel<true, true>), grid, block, 0, stream, s->dev, C, P, s->partial);
-    else if (fast) hipLaunchKernelGGL((rtmi_render_kernel<true, false>), grid, block, 0, stream, s->dev, C, P, s->partial);
-    else if (sigf) hipLaunchKernelGGL((rtmi_render_kernel<false, true>), grid, block, 0, stream, s->dev, C, P, s->partial);
-    else hipLaunchKernelGGL((rtmi_render_kernel<false, false>), grid, block, 0, stream, s->dev, C, P, s->partial);
+    P.stack_depth = s->meta.max_bvh_depth + 1u;
+    P.shade_threshold = p->shade_threshold ? (p->shade_threshold > 64u ? 64u : p->shade_threshold) : 64u;
+    const size_t dyn_lds = (size_t)WAVES_PER_BLOCK * 2u * P.stack_depth * 64u * sizeof(uint32_t);
+    const bool prof = (p->flags & RTMI_FLAG_PROFILE) != 0u, sync = (p->flags & RTMI_FLAG_SYNC) != 0u;
+    if (prof) {
+        if (!p->prof) return fail(RTMI_ERR_INVALID, "RTMI_FLAG_PROFILE needs params.prof");
+        P.prof = reinterpret_cast<unsigned long long *>(p->prof);
+        HIP_TRY(hipMemsetAsync(P.prof, 0, 2 * RTMI_PROF_SLOTS * sizeof(unsigned long long), stream));
+    }
+    // kernel selection: default = two-phase schedule, cooperative traversal when fast-cull is on
+    // (it implements the fast-cull semantics); RTMI_FLAG_SYNC = per-lane traversal; RTMI_FLAG_ASYNC =
+    // per-lane state machine (kept for comparison)
+    const bool async = (p->flags & RTMI_FLAG_ASYNC) != 0u;
+    const bool coop_ok = s->meta.n_prims < (1u << 22) && s->meta.n_nodes < (1u << 25);
+    const bool coop = fast && !sync && !async && coop_ok;
+    P.status = s->status;
+    P.coop_cap = 64u * (s->meta.max_bvh_depth + 2u);
+    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 16u + 128u) * sizeof(uint32_t);
+#define RTMI_LAUNCH(KERN, F, S, PR, LDS) hipLaunchKernelGGL((KERN<F, S, PR>), grid, block, LDS, stream, s->dev, C, P, s->partial)
+#define RTMI_LAUNCH_COOP(S, PR)                                                                                          \
+    do {                                                                                                                 \
+        if (coop_lds > 48u * 1024u)                                                                                      \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi_render_coop<S, PR>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds));                     \
+        hipLaunchKernelGGL((rtmi_render_coop<S, PR>), grid, block, coop_lds, stream, s->dev, C, P, s->partial);          \
+    } while (0)
+    if (coop) {
+        if (prof) RTMI_LAUNCH_COOP(false, true);
+        else if (sigf) RTMI_LAUNCH_COOP(true, false);
+        else RTMI_LAUNCH_COOP(false, false);
+    } else if (!async) {
+        if (prof) { if (fast) RTMI_LAUNCH(rtmi_render_kernel, true, false, true, 0); else RTMI_LAUNCH(rtmi_render_kernel, false, false, true, 0); }
+        else if (fast && sigf) RTMI_LAUNCH(rtmi_render_kernel, true, true, false, 0);
+        else if (fast) RTMI_LAUNCH(rtmi_render_kernel, true, false, false, 0);
+        else if (sigf) RTMI_LAUNCH(rtmi_render_kernel, false, true, false, 0);
+        else RTMI_LAUNCH(rtmi_render_kernel, false, false, false, 0);
+    } else {
+        if (prof) { if (fast) RTMI_LAUNCH(rtmi_render_async, true, false, true, dyn_lds); else RTMI_LAUNCH(rtmi_render_async, false, false, true, dyn_lds); }
+        else if (fast && sigf) RTMI_LAUNCH(rtmi_render_async, true, true, false, dyn_lds);
+        else if (fast) RTMI_LAUNCH(rtmi_render_async, true, false, false, dyn_lds);
+        else if (sigf) RTMI_LAUNCH(rtmi_render_async, false, true, false, dyn_lds);
+        else RTMI_LAUNCH(rtmi_render_async, false, false, false, dyn_lds);
+    }
+#undef RTMI_LAUNCH
+#undef RTMI_LAUNCH_COOP
     HIP_TRY(hipGetLastError());
     if (stats) HIP_TRY(hipEventRecord(s->ev[1], stream));
     const uint32_t ntex = P.ntiles_local * 64u;
@@ -1088,6 +1816,9 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
         }
         stats->samples = pix * p->ns;
         stats->tiles = P.ntiles_local; stats->chunks = chunks; stats->blocks = blocks; stats->reserved = 0;
+        unsigned int st = 0;
+        HIP_TRY(hipMemcpy(&st, s->status, sizeof(st), hipMemcpyDeviceToHost));
+        if (st != 0) return fail(RTMI_ERR_DEVICE, "cooperative traversal pool overflow (results invalid): use RTMI_FLAG_SYNC");
     }
     return RTMI_OK;
 }

@@ -31,7 +31,9 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, abi.RTMI_FLAG_FAST_CULL], ids=["exact", "fast"])
+@pytest.mark.parametrize("flags", [0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL,
+                                   abi.RTMI_FLAG_ASYNC, abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL],
+                         ids=["exact", "coop-fast", "perlane-fast", "async-exact", "async-fast"])
 @pytest.mark.parametrize("name,nx,ny,ns", CASES)
 def test_scene_matches_fp32_oracle(host, orc32, name, nx, ny, ns, flags):
     cam, world = scenes_extra.build(host, name, nx, ny, seed=1)
@@ -71,11 +73,16 @@ def test_fast_cull_equals_exact(host, name, nx, ny, ns):
     cam, world = scenes_extra.build(host, name, nx, ny, seed=1)
     sc = host.lower(world)
     a = sc.render(cam, nx, ny, ns, seed=42, flags=0, sig=True)
-    b = sc.render(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL, sig=True)
-    print(name, "exact %.1f ms, fast %.1f ms" % (a["stats"]["render_ms"], b["stats"]["render_ms"]))
-    assert np.array_equal(a["sig"], b["sig"])
-    assert np.array_equal(a["linear"], b["linear"])
-    assert np.array_equal(a["rgb8"], b["rgb8"])
+    print(name, "exact %.1f ms" % a["stats"]["render_ms"], end="")
+    for label, flags in (("perlane-fast", abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL),
+                         ("coop-fast", abi.RTMI_FLAG_FAST_CULL),
+                         ("async-fast", abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL)):
+        b = sc.render(cam, nx, ny, ns, seed=42, flags=flags, sig=True)
+        print(", %s %.1f ms" % (label, b["stats"]["render_ms"]), end="")
+        assert np.array_equal(a["sig"], b["sig"]), label
+        assert np.array_equal(a["linear"], b["linear"]), label
+        assert np.array_equal(a["rgb8"], b["rgb8"]), label
+    print()
 
 
 def test_result_independent_of_chunking_and_tiling(host):
