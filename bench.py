@@ -59,7 +59,9 @@ def main():
     ap.add_argument("--nx", type=int, default=1920)
     ap.add_argument("--ny", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=1000, help="samples per pixel PER GPU (total spp = spp * gpus)")
-    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=1,
+                    help="rtmi flags; default 1 = RTMI_FLAG_FAST_CULL (two-phase kernel with wave-cooperative, "
+                         "pruned BVH traversal: verified bit-identical to exact mode and to the fp32 oracle)")
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=16)

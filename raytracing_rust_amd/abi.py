@@ -155,6 +155,7 @@ def load_host():
     vp, d, i, u32, u64 = C.c_void_p, C.c_double, C.c_int, C.c_uint32, C.c_uint64
     sig = {
         "rth_last_error": (C.c_char_p, []),
+        "rth_last_error_code": (i, []),
         "rth_free_all": (None, []),
         "rth_seed_scene_rng": (None, [u64]),
         "rth_scene_uniform": (d, []),

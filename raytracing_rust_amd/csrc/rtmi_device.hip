@@ -268,24 +268,23 @@ __device__ __forceinline__ bool cube_test(float4 A, float4 B, const RayF &r, flo
     return any;
 }
 
-// one primitive against (t_min, t_max); pf = prim << 3 | face
+// one primitive against (t_min, t_max); pf = prim << 3 | face.  The three planes are loaded up
+// front (independent addresses): one memory latency instead of up to three dependent ones.
 __device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx, const RayF &r, float time,
                                           float t_min, float t_max, float &t_out, int &pf) {
     const float4 A = sc.prim_a[idx];
+    const float4 B = sc.prim_b[idx];
+    const rtmi_prim_meta M = sc.meta[idx];
     bool h = false;
     int face = 0;
     if (type == RTMI_PRIM_SPHERE) {
         h = sphere_test(r, f3(A.x, A.y, A.z), A.w, t_min, t_max, t_out);
     } else if (type == RTMI_PRIM_MSPHERE) {
-        const float4 B = sc.prim_b[idx];
-        const float inv_dt = sc.meta[idx].inv_dt;
-        h = sphere_test(r, moving_center(A, B, inv_dt, time), A.w, t_min, t_max, t_out);
+        h = sphere_test(r, moving_center(A, B, M.inv_dt, time), A.w, t_min, t_max, t_out);
     } else if (type == RTMI_PRIM_RECT) {
-        const float4 B = sc.prim_b[idx];
-        const int plane = (int)((sc.meta[idx].flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
+        const int plane = (int)((M.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
         h = rect_test_rt(plane, A, B.x, r, t_min, t_max, t_out);
     } else {
-        const float4 B = sc.prim_b[idx];
         h = cube_test(A, B, r, t_min, t_max, t_out, face);
     }
     pf = (idx << 3) | face;
@@ -304,6 +303,20 @@ __device__ __forceinline__ void prof_tick(unsigned long long *prof_lds, int slot
             atomicAdd(&prof_lds[2 * slot], (unsigned long long)__popcll(m));
             atomicAdd(&prof_lds[2 * slot + 1], 64ull);
         }
+    }
+}
+
+// section timing (PROF only): elapsed shader cycles of this wave since the previous stamp are added
+// to slot `slot` (word 0 = cycles, word 1 = number of stamps)
+template <bool PROF>
+__device__ __forceinline__ void prof_time(unsigned long long *prof_lds, int slot, unsigned long long &t_prev) {
+    if (PROF) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&prof_lds[2 * slot], t - t_prev);
+            atomicAdd(&prof_lds[2 * slot + 1], 1ull);
+        }
+        t_prev = __builtin_readcyclecounter();
     }
 }
 
@@ -489,7 +502,7 @@ __device__ __forceinline__ uint32_t coop_enc(int ref) {
 }
 
 // All 64 lanes must call this together.  LDS layout for this wave (uint32 words):
-//   pool [cap][2] | ctx [64][16] floats | best [64] uint64
+//   pool [cap][2] | ctx [64][12] floats | best [64] uint64
 template <bool PROF>
 __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, float scale, bool active, const RayF &R,
                                                float time, float q_min, float q_max, uint32_t *wlds, int cap,
@@ -498,7 +511,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
     const int lane = threadIdx.x & 63;
     volatile uint32_t *pool = wlds;
     float4 *ctx = reinterpret_cast<float4 *>(wlds + 2 * cap);
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(wlds + 2 * cap + 64 * 16);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(wlds + 2 * cap + 64 * 12);
 
     const unsigned long long m_act = __ballot(active);
     have = false;
@@ -506,11 +519,11 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
     // ---- publish ray contexts, push roots
     best[lane] = COOP_SENTINEL;
     if (active) {
-        const float m_abs = scale * (1.0f / 8192.0f) * __builtin_sqrtf(R.inv_a);
-        ctx[lane * 4 + 0] = make_float4(R.o.x, R.o.y, R.o.z, R.a);
-        ctx[lane * 4 + 1] = make_float4(R.d.x, R.d.y, R.d.z, R.inv_a);
-        ctx[lane * 4 + 2] = make_float4(R.inv_d.x, R.inv_d.y, R.inv_d.z, time);
-        ctx[lane * 4 + 3] = make_float4(q_min, q_max, m_abs, 0.0f);
+        // 48 B per ray; a, inv_a and the pruning margin are recomputed by the worker with the same
+        // operations on the same values (bit-identical), which keeps the wave's LDS under 10 KB
+        ctx[lane * 3 + 0] = make_float4(R.o.x, R.o.y, R.o.z, time);
+        ctx[lane * 3 + 1] = make_float4(R.d.x, R.d.y, R.d.z, q_min);
+        ctx[lane * 3 + 2] = make_float4(R.inv_d.x, R.inv_d.y, R.inv_d.z, q_max);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u));
         pool[2 * pos] = ((uint32_t)lane << 26) | (uint32_t)root;
         pool[2 * pos + 1] = __float_as_uint(q_min); // entry distance of the root: conservative
@@ -551,11 +564,13 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
         float push_t = 0.0f;
         if (cur != COOP_NONE) {
             if (ray != cray) { // switch ray context
-                const float4 c0 = ctx[ray * 4 + 0], c1 = ctx[ray * 4 + 1], c2 = ctx[ray * 4 + 2], c3 = ctx[ray * 4 + 3];
-                W.o = f3(c0.x, c0.y, c0.z); W.a = c0.w;
-                W.d = f3(c1.x, c1.y, c1.z); W.inv_a = c1.w;
-                W.inv_d = f3(c2.x, c2.y, c2.z); wtime = c2.w;
-                wqmin = c3.x; wqmax = c3.y; wmabs = c3.z;
+                const float4 c0 = ctx[ray * 3 + 0], c1 = ctx[ray * 3 + 1], c2 = ctx[ray * 3 + 2];
+                W.o = f3(c0.x, c0.y, c0.z); wtime = c0.w;
+                W.d = f3(c1.x, c1.y, c1.z); wqmin = c1.w;
+                W.inv_d = f3(c2.x, c2.y, c2.z); wqmax = c2.w;
+                W.a = dot(W.d, W.d);
+                W.inv_a = 1.0f / W.a;
+                wmabs = scale * (1.0f / 8192.0f) * __builtin_sqrtf(W.inv_a);
                 cray = ray;
             }
             // the ray's best hit so far -> pruning limit
@@ -1072,9 +1087,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
 // Same schedule as rtmi_render_kernel; the item scan of phase A is executed by ALL lanes (lanes
 // without a pending query are workers for the others' BVH traversals).
 // ----------------------------------------------------------------------------------
-template <bool SIG, bool PROF>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_coop(DevScene sc, DevCamera cam, DevParams P,
-                                                                         double *__restrict__ partial) {
+template <bool SIG, bool PROF, int WPS>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(DevScene sc, DevCamera cam, DevParams P,
+                                                                              double *__restrict__ partial) {
     __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
     unsigned long long *prof = prof_lds;
     if (PROF) {
@@ -1085,7 +1100,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_coop(DevScen
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int cap = (int)P.coop_cap;
-    uint32_t *wlds = lds_dyn + (size_t)wave * (2u * cap + 64u * 16u + 128u);
+    uint32_t *wlds = lds_dyn + (size_t)wave * (2u * cap + 64u * 12u + 128u);
     unsigned long long sig = 0ull;
     const LaneJob J = lane_job(P, wave, lane);
     if (!PROF && !J.wave_has_work) return;
@@ -1102,6 +1117,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_coop(DevScen
     float closest = RTMI_FLT_MAX;
     int best_item = -1, best_pf = 0;
     bool best_medium = false;
+    unsigned long long tstamp = PROF ? __builtin_readcyclecounter() : 0ull;
 
     for (;;) {
         // ================= phase A =================
@@ -1109,10 +1125,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_coop(DevScen
             const bool need = !have_hit && !done;
             if (__ballot(need) == 0ull) break;
             prof_tick<PROF>(prof, 0, need);
+            prof_time<PROF>(prof, 31, tstamp); // loop overhead / phase switching
             if (need && !alive) {
                 camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
                 alive = true;
             }
+            prof_time<PROF>(prof, 25, tstamp); // camera samples
             RayF W;
             W.o = pa.ro; W.d = pa.rd;
             ray_derive(W);
@@ -1130,6 +1148,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_coop(DevScen
                     if (geom_query_coop<PROF>(sc, I, need, R, pa.rtime, P.t_min, closest, wlds, cap, t, pf, overflow, prof, slot)) {
                         closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                     }
+                    prof_time<PROF>(prof, I.kind == RTMI_ITEM_BVH ? (it == 0 ? 27 : 28) : 26, tstamp);
                 } else {
                     // ConstantMedium::hit — medium.rs:28-56
                     float t1 = 0.0f, t2 = 0.0f, tm;
@@ -1141,6 +1160,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_coop(DevScen
                             closest = tm; best_item = (int)it; best_medium = true;
                         }
                     }
+                    prof_time<PROF>(prof, 29, tstamp); // media
                 }
             }
             if (need) {
@@ -1166,6 +1186,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_coop(DevScen
                 done = s >= J.s_end;
             }
         }
+        prof_time<PROF>(prof, 30, tstamp); // shading
     }
     if (__ballot(overflow) != 0ull && lane == 0) atomicAdd(P.status, 1u); // reported loudly by the host
 
@@ -1746,7 +1767,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     const bool fast = (p->flags & RTMI_FLAG_FAST_CULL) != 0u, sigf = (p->flags & RTMI_FLAG_PATH_SIG) != 0u;
     const dim3 grid(blocks), block(64 * WAVES_PER_BLOCK);
     P.stack_depth = s->meta.max_bvh_depth + 1u;
-    P.shade_threshold = p->shade_threshold ? (p->shade_threshold > 64u ? 64u : p->shade_threshold) : 64u;
+    P.shade_threshold = p->shade_threshold ? (p->shade_threshold > 64u ? 64u : p->shade_threshold) : 1u;
     const size_t dyn_lds = (size_t)WAVES_PER_BLOCK * 2u * P.stack_depth * 64u * sizeof(uint32_t);
     const bool prof = (p->flags & RTMI_FLAG_PROFILE) != 0u, sync = (p->flags & RTMI_FLAG_SYNC) != 0u;
     if (prof) {
@@ -1762,19 +1783,22 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     const bool coop = fast && !sync && !async && coop_ok;
     P.status = s->status;
     P.coop_cap = 64u * (s->meta.max_bvh_depth + 2u);
-    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 16u + 128u) * sizeof(uint32_t);
+    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u) * sizeof(uint32_t);
 #define RTMI_LAUNCH(KERN, F, S, PR, LDS) hipLaunchKernelGGL((KERN<F, S, PR>), grid, block, LDS, stream, s->dev, C, P, s->partial)
-#define RTMI_LAUNCH_COOP(S, PR)                                                                                          \
+#define RTMI_LAUNCH_COOP(S, PR, W)                                                                                       \
     do {                                                                                                                 \
         if (coop_lds > 48u * 1024u)                                                                                      \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi_render_coop<S, PR>),                        \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi_render_coop<S, PR, W>),                     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds));                     \
-        hipLaunchKernelGGL((rtmi_render_coop<S, PR>), grid, block, coop_lds, stream, s->dev, C, P, s->partial);          \
+        hipLaunchKernelGGL((rtmi_render_coop<S, PR, W>), grid, block, coop_lds, stream, s->dev, C, P, s->partial);       \
     } while (0)
     if (coop) {
-        if (prof) RTMI_LAUNCH_COOP(false, true);
-        else if (sigf) RTMI_LAUNCH_COOP(true, false);
-        else RTMI_LAUNCH_COOP(false, false);
+        const uint32_t wps = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
+        if (prof) RTMI_LAUNCH_COOP(false, true, 3);
+        else if (sigf) RTMI_LAUNCH_COOP(true, false, 4);
+        else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3);
+        else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5);
+        else RTMI_LAUNCH_COOP(false, false, 4);
     } else if (!async) {
         if (prof) { if (fast) RTMI_LAUNCH(rtmi_render_kernel, true, false, true, 0); else RTMI_LAUNCH(rtmi_render_kernel, false, false, true, 0); }
         else if (fast && sigf) RTMI_LAUNCH(rtmi_render_kernel, true, true, false, 0);

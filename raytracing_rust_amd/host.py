@@ -178,7 +178,7 @@ class Host:
 
     def _raise(self):
         msg = (self.lib.rth_last_error() or b"").decode()
-        raise HostError(msg)
+        raise {2: Panic, 3: Unsupported}.get(self.lib.rth_last_error_code(), HostError)(msg)
 
     def _check(self, rc):
         if rc == 0:
@@ -259,11 +259,7 @@ class Host:
 
     def BVHNode(self, hittables, time0, time1):
         arr = (C.c_void_p * len(hittables))(*[h.h for h in hittables])
-        h = self.lib.rth_bvh(arr, len(hittables), time0, time1)
-        if not h:
-            msg = (self.lib.rth_last_error() or b"").decode()
-            raise Panic(msg)
-        return _Obj(self, h, tuple(hittables))
+        return _Obj(self, self.lib.rth_bvh(arr, len(hittables), time0, time1), tuple(hittables))
 
     def Camera(self, look_from, look_at, view_up, vertical_fov, aspect, aperture, focus_dist, time0, time1):
         f, a, u = _d3(look_from), _d3(look_at), _d3(view_up)

@@ -16,6 +16,7 @@ enum { RTH_OK = 0, RTH_ERROR = 1, RTH_PANIC = 2, RTH_UNSUPPORTED = 3 };
 
 namespace {
 thread_local std::string g_err;
+thread_local int g_code = 0;
 
 struct Obj {
     enum Kind { TEX, MAT, HIT, LIST, CAM, LOWERED } kind;
@@ -37,9 +38,10 @@ Obj *reg(Obj *o) {
 }
 int set_err(const std::exception &e) {
     g_err = e.what();
-    if (dynamic_cast<const Panic *>(&e)) return RTH_PANIC;
-    if (dynamic_cast<const Unsupported *>(&e)) return RTH_UNSUPPORTED;
-    return RTH_ERROR;
+    g_code = RTH_ERROR;
+    if (dynamic_cast<const Panic *>(&e)) g_code = RTH_PANIC;
+    if (dynamic_cast<const Unsupported *>(&e)) g_code = RTH_UNSUPPORTED;
+    return g_code;
 }
 template <typename F>
 void *guard_new(F f) {
@@ -78,6 +80,7 @@ MaterialPtr M(void *h) {
 } // namespace
 
 RTH_API const char *rth_last_error(void) { return g_err.c_str(); }
+RTH_API int rth_last_error_code(void) { return g_code; }
 RTH_API void rth_free_all(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (Obj *o : g_objs) {

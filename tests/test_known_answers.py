@@ -1,0 +1,180 @@
+"""T3: known-answer tests derived by hand from the formulas in the reference (file:line cited per
+case), run against BOTH CPU restatements: the oracle (C) and the C++ host mirror.  They pin the
+semantics the reference's own tests never assert, including its quirks."""
+import math
+
+import numpy as np
+import pytest
+
+PI = math.pi
+
+
+@pytest.fixture(params=["oracle64", "mirror"])
+def api(request, host, orc64):
+    return orc64 if request.param == "oracle64" else host
+
+
+def _lam(api, rgb=(0.5, 0.5, 0.5)):
+    return api.Lambertian(api.SolidTexture(*rgb))
+
+
+def test_sphere_hit_record(api):  # sphere.rs:37-77, 9-15
+    s = api.Sphere((0, 0, 0), 1.0, _lam(api))
+    h = api.hit(s, (0, 0, -3), (0, 0, 1), t_min=0.001)
+    assert h["t"] == 2.0
+    assert np.allclose(h["p"], (0, 0, -1)) and np.allclose(h["normal"], (0, 0, -1))
+    assert h["u"] == pytest.approx(1.0 - (math.atan2(-1.0, 0.0) + PI) / (2 * PI))  # 0.75
+    assert h["v"] == pytest.approx((0.0 + 2.0 / PI) / PI)  # FRAC_2_PI, not FRAC_PI_2 (sphere.rs:13)
+    # from inside: first root rejected (t < t_min), second accepted; normal stays OUTWARD (never flipped)
+    h = api.hit(s, (0, 0, 0), (0, 0, 1))
+    assert h["t"] == 1.0 and np.allclose(h["normal"], (0, 0, 1))
+    # strict comparisons: t == t_max is NOT a hit (sphere.rs:48), tangent ray (disc == 0) misses (:45)
+    assert api.hit(s, (0, 0, -3), (0, 0, 1), t_max=2.0) is None
+    assert api.hit(s, (1, 0, -3), (0, 0, 1)) is None
+
+
+def test_moving_sphere_center_and_bbox(api):  # sphere.rs:115-118, 165-174
+    m = api.MovingSphere((0, 0, 0), (0, 2, 0), 0.0, 1.0, 0.5, _lam(api))
+    h = api.hit(m, (0, 1, -3), (0, 0, 1), time=0.5)
+    assert h["t"] == 2.5 and np.allclose(h["p"], (0, 1, -0.5))
+    assert api.hit(m, (0, 1, -3), (0, 0, 1), time=0.0) is None
+    mn, mx = api.bounding_box(m, 0.0, 1.0)
+    assert np.allclose(mn, (-0.5, -0.5, -0.5)) and np.allclose(mx, (0.5, 2.5, 0.5))
+
+
+def test_rect_closed_intervals_normal_and_degenerate(api):  # rect.rs:39-69
+    r = api.Rect(api.PLANE_XY, 0.0, 0.0, 2.0, 4.0, 5.0, _lam(api))
+    h = api.hit(r, (1, 1, 0), (0, 0, 1))
+    assert h["t"] == 5.0 and h["u"] == 0.5 and h["v"] == 0.25
+    assert np.allclose(h["normal"], (0, 0, 1))  # +e_k always, whatever the ray side (:58-59)
+    assert np.allclose(api.hit(r, (1, 1, 10), (0, 0, -1))["normal"], (0, 0, 1))
+    assert api.hit(r, (2, 4, 0), (0, 0, 1)) is not None        # edges are inside: x > x1 rejects (:51)
+    assert api.hit(r, (1, 1, 0), (0, 0, 1), t_max=5.0) is not None  # t == t_max accepted: `t > t_max` rejects (:47)
+    assert api.hit(r, (1, 1, 0), (0, 0, 1), t_max=4.999) is None
+    deg = api.Rect(api.PLANE_ZX, 147.0, 412.0, 123.0, 423.0, 554.0, _lam(api))  # x0 > x1: final_scene's light
+    assert api.hit(deg, (415, 0, 130), (0, 1, 0)) is None
+    # ZX plane: (k, a, b) = (y, z, x) (rect.rs:42); bbox ignores the plane (:72-73)
+    zx = api.Rect(api.PLANE_ZX, 1.0, 10.0, 2.0, 20.0, 3.0, _lam(api))
+    assert api.hit(zx, (15, 0, 1.5), (0, 1, 0))["t"] == 3.0
+    mn, mx = api.bounding_box(zx)
+    assert np.allclose(mn, (1, 10, 3 - 1e-4)) and np.allclose(mx, (2, 20, 3 + 1e-4))
+
+
+def test_list_order_and_tie_rules(api):  # hittable.rs:37-47 with rect.rs:47 / sphere.rs:48
+    red, green = _lam(api, (1, 0, 0)), _lam(api, (0, 1, 0))
+    world = api.HittableList()
+    world.push(api.FlipNormals(api.Rect(api.PLANE_ZX, 0, 0, 10, 10, 0.0, red)))
+    world.push(api.Rect(api.PLANE_ZX, 0, 0, 10, 10, 0.0, green))
+    h = api.hit(world, (5, 5, 5), (0, -1, 0))
+    assert h["t"] == 5.0 and np.allclose(h["normal"], (0, 1, 0))  # coincident rects: the LATER one wins
+    world2 = api.HittableList()
+    world2.push(api.Sphere((0, 0, 0), 1.0, red))
+    world2.push(api.Sphere((0, 0, 0), 1.0, green))
+    from raytracing_rust_amd.host import Host
+    if not isinstance(api, Host):
+        assert api.hit(world2, (0, 0, -3), (0, 0, 1))["mat_kind"] == 0
+    assert api.hit(world2, (0, 0, -3), (0, 0, 1))["t"] == 2.0  # coincident spheres: the EARLIER one stays
+
+
+def test_cube_faces_have_unflipped_normals(api):  # cube.rs:21-74
+    c = api.Cube((0, 0, 0), (1, 2, 3), _lam(api))
+    h = api.hit(c, (0.5, 1, -5), (0, 0, 1))
+    assert h["t"] == 5.0 and np.allclose(h["normal"], (0, 0, 1))   # min-z face: normal points INTO the box
+    h = api.hit(c, (0.5, 1, 9), (0, 0, -1))
+    assert h["t"] == 6.0 and np.allclose(h["normal"], (0, 0, 1))
+    mn, mx = api.bounding_box(c)
+    assert np.allclose(mn, (0, 0, 0)) and np.allclose(mx, (1, 2, 3))
+
+
+def test_translate_rotate_and_rotate_bbox_bug(api):  # traslate.rs:18-24, rotate.rs:85-113, :36-37
+    s = api.Sphere((0, 0, 0), 1.0, _lam(api))
+    t = api.Traslate(s, (10, 0, 0))
+    h = api.hit(t, (10, 0, -3), (0, 0, 1))
+    assert h["t"] == 2.0 and np.allclose(h["p"], (10, 0, -1))
+    r = api.Rotate(api.AXIS_Y, api.Rect(api.PLANE_XY, -1, -1, 1, 1, 2.0, _lam(api)), 90.0)
+    # rotate.rs:91-98: o'[z] = cos*o[z] + sin*o[x], o'[x] = -sin*o[z] + cos*o[x]; theta = 90 deg
+    h = api.hit(r, (-5, 0, 0), (1, 0, 0))
+    assert h is not None and h["t"] == pytest.approx(7.0)
+    assert np.allclose(h["normal"], (1, 0, 0), atol=1e-12)
+    mn, mx = api.bounding_box(r)
+    assert mn[0] < -1e300 and mx[0] > 1e300  # min/max initialised the wrong way round: never updated
+
+
+def test_aabb_via_bvh_and_bvh_panics_without_bbox(api):  # aabb.rs:31-44, bvh.rs:17-66
+    mats = _lam(api)
+    api.seed_scene_rng(3)
+    objs = [api.Sphere((3.0 * i, 0, 0), 1.0, mats) for i in range(5)]
+    bvh = api.BVHNode(objs, 0.0, 1.0)
+    mn, mx = api.bounding_box(bvh)
+    assert np.allclose(mn, (-1, -1, -1)) and np.allclose(mx, (13, 1, 1))
+    assert api.hit(bvh, (6, 0, -5), (0, 0, 1))["t"] == 4.0
+    assert api.hit(bvh, (6, 5, -5), (0, 0, 1)) is None
+    # equal t in both children -> the right one (bvh.rs:76-80); a BVH over one object tests it twice (:44-45)
+    one = api.BVHNode([api.Sphere((0, 0, 0), 1.0, mats)], 0.0, 1.0)
+    assert api.hit(one, (0, 0, -3), (0, 0, 1))["t"] == 2.0
+
+
+def test_materials(api):  # material.rs
+    p, n = np.array([0.0, 0, 0]), np.array([0.0, 0, 1.0])
+    rec = {"t": 1.0, "u": 0.0, "v": 0.0, "p": p, "normal": n}
+    metal = api.Metal(api.SolidTexture(0.8, 0.6, 0.4), 0.0)
+    s = api.scatter(metal, (0, 0, 1), (1, 0, -1), 0.25, rec)
+    inv = 1 / math.sqrt(2)
+    assert np.allclose(s["d"], (inv, 0, inv)) and s["time"] == 0.25 and np.allclose(s["attenuation"], (0.8, 0.6, 0.4))
+    assert api.scatter(metal, (0, 0, -1), (1, 0, 1), 0.0, rec) is None  # reflected.n <= 0: absorbed (:81-86)
+    fuzzy = api.Metal(api.SolidTexture(1, 1, 1), 10.0)  # fuzz clamps to 1.0 (:70): |d - mirror| < 1
+    s = api.scatter(fuzzy, (0, 0, 1), (0, 0, -1), 0.0, rec, seed=9)
+    assert s is None or np.linalg.norm(s["d"] - np.array([0, 0, 1.0])) < 1.0
+    light = api.DiffuseLight(api.SolidTexture(4, 5, 6))
+    assert api.scatter(light, (0, 0, 1), (0, 0, -1), 0.0, rec) is None
+    assert np.allclose(api.emitted(light, 0, 0, (0, 0, 0)), (4, 5, 6))
+    assert np.allclose(api.emitted(metal, 0, 0, (0, 0, 0)), (0, 0, 0))
+    glass = api.Dielectric(1.5)
+    s = api.scatter(glass, (0, 0, 1), (0, 0, -2), 0.0, rec, seed=1)  # normal incidence from outside
+    assert np.allclose(s["attenuation"], (1, 1, 1))
+    # schlick(1, 1.5) = 0.04: refraction keeps direction (0,0,-1) (unit), reflection returns un-normalised (0,0,2)
+    assert np.allclose(s["d"], (0, 0, -1)) or np.allclose(s["d"], (0, 0, 2))
+    lam = api.Lambertian(api.SolidTexture(0.1, 0.2, 0.3))
+    s = api.scatter(lam, (0, 0, 1), (0, 0, -1), 0.5, rec, seed=3)
+    assert np.linalg.norm(s["d"] - n) < 1.0 and np.allclose(s["o"], p) and s["time"] == 0.5
+    iso = api.Isotropic(api.SolidTexture(0.1, 0.2, 0.3))
+    s = api.scatter(iso, (0, 0, 1), (0, 0, -1), 0.0, rec, seed=3)
+    assert np.linalg.norm(s["d"]) < 1.0  # not normalised (:166)
+
+
+def test_textures(api):  # texture.rs
+    ck = api.CheckerTexture(api.SolidTexture(1, 0, 0), api.SolidTexture(0, 1, 0))
+    p = (0.1, 0.1, 0.1)  # sin(1)^3 > 0 -> even
+    assert np.allclose(api.tex_value(ck, 0, 0, p), (0, 1, 0))
+    assert np.allclose(api.tex_value(ck, 0, 0, (-0.1, 0.1, 0.1)), (1, 0, 0))
+    data = np.arange(2 * 2 * 3, dtype=np.uint8) * 20
+    im = api.ImageTexture(data, 2, 2)
+    assert np.allclose(api.tex_value(im, 0.0, 1.0, (0, 0, 0)), data[0:3] / 255.0)       # i=0, j=(1-v)*ny=0
+    assert np.allclose(api.tex_value(im, 0.99, 0.0, (0, 0, 0)), data[9:12] / 255.0)     # clamped to nx-1, ny-1
+    assert np.allclose(api.tex_value(im, -3.0, 7.0, (0, 0, 0)), data[0:3] / 255.0)      # `as usize` saturates at 0
+    assert np.allclose(api.tex_value(im, float("nan"), 1.0, (0, 0, 0)), data[0:3] / 255.0)
+
+
+def test_perlin_tables_and_noise_range(api):  # perlin.rs
+    api.seed_scene_rng(11)
+    nt = api.NoiseTexture(4.0)
+    rv, pm = api.perlin_tables(nt)
+    assert np.allclose(np.linalg.norm(rv, axis=1), 1.0)
+    for k in range(3):
+        assert sorted(pm[k]) == list(range(256))
+    v = api.tex_value(nt, 0, 0, (0.3, 1.7, -2.2))  # negative coordinate: floor(p) as usize -> 0 (perlin.rs:83-85)
+    assert v[0] == v[1] == v[2] and 0.0 <= v[0] <= 1.0
+
+
+def test_camera_new_and_get_ray(api):  # camera.rs:21-67
+    cam = api.Camera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 16.0 / 9.0, 0.0, 10.0, 0.0, 1.0)
+    st = api.camera_state(cam) if hasattr(api, "camera_state") else cam.state()
+    origin, llc, hor, ver, u, v = (st[3 * i:3 * i + 3] for i in range(6))
+    hh = 10.0 * math.tan(math.radians(20.0) / 2)
+    assert np.allclose(origin, (13, 2, 3)) and st[20] == 0.0
+    assert np.linalg.norm(hor) == pytest.approx(2 * hh * 16 / 9) and np.linalg.norm(ver) == pytest.approx(2 * hh)
+    w = np.array([13, 2, 3.0]) / np.linalg.norm([13, 2, 3.0])
+    assert np.allclose(llc, origin - 0.5 * hor - 0.5 * ver - 10.0 * w)
+    ray = api.get_ray(cam, 0.5, 0.5, seed=4) if hasattr(api, "get_ray") else cam.get_ray(0.5, 0.5, seed=4)
+    assert np.allclose(ray[:3], origin)  # lens_radius == 0: no disk draw (camera.rs:54-55)
+    assert np.allclose(ray[3:6], -10.0 * w) and 0.0 <= ray[6] < 1.0

@@ -1,0 +1,84 @@
+"""include/rtmi_math.h: accuracy of the fp32 transcendental contract against libm on the ranges
+the path uses (CPU), and bit-equality of device and host evaluation (GPU)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracing_rust_amd import abi
+
+
+def _host_eval(orc32, name, *args):
+    fn = getattr(orc32.lib, name)
+    return np.array([fn(*[float(a[i]) for a in args]) for i in range(len(args[0]))], np.float32)
+
+
+def test_accuracy_against_libm(orc32):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-60000, 60000, 20000), rng.uniform(-10, 10, 20000), [0.0, -0.0, 1e-30]]).astype(np.float32)
+    s = _host_eval(orc32, "orc_rtmi_sinf", x)
+    # absolute error: Cody-Waite reduction loses ~ulp(x) of phase
+    assert np.max(np.abs(s - np.sin(x.astype(np.float64))) / (1.0 + np.abs(x) * 6e-8 / 1e-7)) < 1e-6
+    u = ((rng.integers(1, 1 << 24, 40000)).astype(np.float32) * np.float32(2.0 ** -24))
+    l = _host_eval(orc32, "orc_rtmi_logf", u)
+    assert np.max(np.abs(l - np.log(u.astype(np.float64))) / np.maximum(1e-3, np.abs(np.log(u.astype(np.float64))))) < 3e-7
+    assert orc32.lib.orc_rtmi_logf(0.0) == -np.inf
+    n = rng.normal(size=(20000, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n = n.astype(np.float32)
+    a = _host_eval(orc32, "orc_rtmi_atan2f", n[:, 2], n[:, 0])
+    assert np.max(np.abs(a - np.arctan2(n[:, 2].astype(np.float64), n[:, 0].astype(np.float64)))) < 1e-6
+    y = _host_eval(orc32, "orc_rtmi_asinf", n[:, 1])
+    assert np.max(np.abs(y - np.arcsin(n[:, 1].astype(np.float64)))) < 1e-6
+    assert np.isnan(orc32.lib.orc_rtmi_asinf(1.0000001))  # like Rust's asin outside [-1,1]
+
+
+def test_u01_is_24_bit_exact():
+    from raytracing_rust_amd.philox import Stream
+
+    s = Stream(3)
+    for _ in range(100):
+        w = s.u32()
+        u = (w >> 8) * 2.0 ** -24
+        assert np.float32(u) == u and 0.0 <= u < 1.0
+
+
+@pytest.mark.gpu
+def test_device_equals_host_bit_for_bit(orc32):
+    lib = abi.load_rtmi()
+    rng = np.random.default_rng(1)
+    n = 1 << 16
+    cases = {
+        0: (np.concatenate([rng.uniform(-60000, 60000, n // 2), rng.uniform(-8, 8, n // 2)]).astype(np.float32), None, "orc_rtmi_sinf"),
+        1: ((rng.integers(0, 1 << 24, n)).astype(np.float32) * np.float32(2.0 ** -24), None, "orc_rtmi_logf"),
+        2: (rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32), "orc_rtmi_atan2f"),
+        3: (rng.uniform(-1.0, 1.0, n).astype(np.float32), None, "orc_rtmi_asinf"),
+    }
+    for op, (x, y, name) in cases.items():
+        out = np.zeros(n, np.float32)
+        rc = lib.rtmi_probe_math(op, x.ctypes.data, y.ctypes.data if y is not None else None, out.ctypes.data, n)
+        assert rc == 0, lib.rtmi_last_error()
+        ref = _host_eval(orc32, name, *([x] if y is None else [x, y]))
+        same = (out.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(out) & np.isnan(ref))
+        assert same.all(), "%s: %d of %d differ" % (name, int((~same).sum()), n)
+    # IEEE division and square root: device == numpy float32 (correctly rounded on both)
+    a = rng.normal(size=n).astype(np.float32) * 1000
+    b = rng.normal(size=n).astype(np.float32)
+    out = np.zeros(n, np.float32)
+    assert lib.rtmi_probe_math(4, a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
+    assert np.array_equal(out.view(np.uint32), (a / b).view(np.uint32))
+    pos = np.abs(a)
+    assert lib.rtmi_probe_math(5, pos.ctypes.data, None, out.ctypes.data, n) == 0
+    assert np.array_equal(out.view(np.uint32), np.sqrt(pos).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_device_philox_kat():
+    lib = abi.load_rtmi()
+    from test_philox import KAT
+
+    ctr = np.array([k[0] for k in KAT], np.uint32)
+    key = np.array([k[1] for k in KAT], np.uint32)
+    out = np.zeros((len(KAT), 4), np.uint32)
+    assert lib.rtmi_probe_philox(ctr.ctypes.data, key.ctypes.data, out.ctypes.data, len(KAT)) == 0
+    assert out.tolist() == [k[2] for k in KAT]
