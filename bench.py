@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=16)
-    ap.add_argument("--cpu-spp", type=int, default=48)
+    ap.add_argument("--cpu-spp", type=int, default=144)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ppm-out", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "rtmi_bench.ppm"))
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
@@ -204,7 +204,7 @@ def main():
         "unit": "GB/s",
         "frac": round(achieved_gbs / roofline.HBM_PEAK_GBS, 6),
         "traffic": traffic,
-        "kernel": "rtmi_render_kernel",
+        "kernel": "rtmi_render_coop" if (args.flags & 1) and not (args.flags & 24) else ("rtmi_render_async" if args.flags & 16 else "rtmi_render_kernel"),
         "bytes_per_sample": round(work["bytes"], 2),
         "flops_per_sample": round(work["flops"], 2),
         "samples_per_launch": samples_per_launch,
