@@ -25,7 +25,7 @@
 #include "rtmi_math.h"
 
 #define RTMI_FLT_MAX 3.40282346638528859811704183484516925e+38f
-#define WAVES_PER_BLOCK 4
+#define WAVES_PER_BLOCK 2
 
 // ----------------------------------------------------------------------------------
 // small vector type with explicit operation order (nalgebra Vector3 semantics)
@@ -117,18 +117,52 @@ __device__ __forceinline__ float rng_uniform(Rng &g, uint32_t k0, uint32_t k1) {
     return rtmi_u01(w);
 }
 
-// src/util.rs:4-13
+// The next THREE (resp. TWO) consecutive words of the stream with at most ONE Philox evaluation
+// for the whole wavefront.  Calling rng_uniform three times evaluates Philox up to three times per
+// wavefront (lanes sit at different positions of their 4-word blocks, so at every call some lane
+// needs a refill and the others wait).  Same stream, same words, same order: bit-identical.
+__device__ __forceinline__ void rng_take3(Rng &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+    uint32_t n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
+    const uint32_t pos = g.pos;
+    if (pos >= 2u) { // fewer than three words left in the current block
+        philox(g.block, g.sample, g.pixel, 0u, k0, k1, n0, n1, n2, n3);
+        g.block++;
+    }
+    w0 = pos == 0u ? g.b0 : (pos == 1u ? g.b1 : (pos == 2u ? g.b2 : (pos == 3u ? g.b3 : n0)));
+    w1 = pos == 0u ? g.b1 : (pos == 1u ? g.b2 : (pos == 2u ? g.b3 : (pos == 3u ? n0 : n1)));
+    w2 = pos == 0u ? g.b2 : (pos == 1u ? g.b3 : (pos == 2u ? n0 : (pos == 3u ? n1 : n2)));
+    if (pos >= 2u) { g.b0 = n0; g.b1 = n1; g.b2 = n2; g.b3 = n3; g.pos = pos - 1u; } // 2->1, 3->2, 4->3
+    else g.pos = pos + 3u;
+}
+__device__ __forceinline__ void rng_take2(Rng &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1) {
+    uint32_t n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
+    const uint32_t pos = g.pos;
+    if (pos >= 3u) {
+        philox(g.block, g.sample, g.pixel, 0u, k0, k1, n0, n1, n2, n3);
+        g.block++;
+    }
+    w0 = pos == 0u ? g.b0 : (pos == 1u ? g.b1 : (pos == 2u ? g.b2 : (pos == 3u ? g.b3 : n0)));
+    w1 = pos == 0u ? g.b1 : (pos == 1u ? g.b2 : (pos == 2u ? g.b3 : (pos == 3u ? n0 : n1)));
+    if (pos >= 3u) { g.b0 = n0; g.b1 = n1; g.b2 = n2; g.b3 = n3; g.pos = pos - 2u; } // 3->1, 4->2
+    else g.pos = pos + 2u;
+}
+
+// src/util.rs:4-13 (draws x, y, z per trial)
 __device__ __forceinline__ F3 random_in_unit_sphere(Rng &g, uint32_t k0, uint32_t k1) {
     for (;;) {
-        float x = rng_uniform(g, k0, k1), y = rng_uniform(g, k0, k1), z = rng_uniform(g, k0, k1);
+        uint32_t w0, w1, w2;
+        rng_take3(g, k0, k1, w0, w1, w2);
+        const float x = rtmi_u01(w0), y = rtmi_u01(w1), z = rtmi_u01(w2);
         F3 p = f3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
         if (dot(p, p) < 1.0f) return p;
     }
 }
-// src/util.rs:15-24
+// src/util.rs:15-24 (draws x, y per trial)
 __device__ __forceinline__ F3 random_in_unit_disk(Rng &g, uint32_t k0, uint32_t k1) {
     for (;;) {
-        float x = rng_uniform(g, k0, k1), y = rng_uniform(g, k0, k1);
+        uint32_t w0, w1;
+        rng_take2(g, k0, k1, w0, w1);
+        const float x = rtmi_u01(w0), y = rtmi_u01(w1);
         F3 p = f3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 0.0f);
         if (dot(p, p) < 1.0f) return p;
     }
@@ -792,8 +826,10 @@ struct Path { // one camera path in flight (per lane)
 __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevParams &P, Rng &g, uint32_t k0, uint32_t k1,
                                               uint32_t s, uint32_t pixel, uint32_t px, uint32_t j, Path &pa) {
     rng_init(g, s, pixel);
-    const float u = ((float)px + rng_uniform(g, k0, k1)) / (float)P.nx;
-    const float v = ((float)j + rng_uniform(g, k0, k1)) / (float)P.ny;
+    uint32_t wu, wv;
+    rng_take2(g, k0, k1, wu, wv); // u then v — tests/test.rs:66-67
+    const float u = ((float)px + rtmi_u01(wu)) / (float)P.nx;
+    const float v = ((float)j + rtmi_u01(wv)) / (float)P.ny;
     F3 origin = cam.origin;
     if (cam.lens_radius != 0.0f) {
         const F3 rdk = random_in_unit_disk(g, k0, k1) * cam.lens_radius;
