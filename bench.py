@@ -67,6 +67,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=16)
     ap.add_argument("--cpu-spp", type=int, default=144)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one GPU per rank) for real runs; gloo only to rehearse N > 1 on a box with "
+                         "fewer GPUs than ranks (ranks share GPUs, the gather goes through host memory)")
     ap.add_argument("--ppm-out", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "rtmi_bench.ppm"))
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     args = ap.parse_args()
@@ -79,9 +82,11 @@ def main():
 
     if not torch.cuda.is_available() or abi.load_rtmi().rtmi_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the rtmi render path has no CPU fallback")
-    rank, world, local_rank = rdist.init_process_group("nccl")
+    rank, world, local_rank = rdist.init_process_group(args.backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -106,6 +111,9 @@ def main():
         scene.render_device(cam, params, local.data_ptr(), stream.cuda_stream)
         if events is not None:
             events[1].record(stream)
+        if args.backend == "gloo" and world > 1:
+            torch.cuda.synchronize(device)
+            return rdist.gather_framebuffer(local.cpu(), rank, world)
         return rdist.gather_framebuffer(local, rank, world)
 
     def fence():
@@ -123,7 +131,7 @@ def main():
         gathered = step(evs[k])
     fence()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

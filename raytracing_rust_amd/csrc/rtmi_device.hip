@@ -25,7 +25,7 @@
 #include "rtmi_math.h"
 
 #define RTMI_FLT_MAX 3.40282346638528859811704183484516925e+38f
-#define WAVES_PER_BLOCK 2
+#define WAVES_PER_BLOCK 1
 
 // ----------------------------------------------------------------------------------
 // small vector type with explicit operation order (nalgebra Vector3 semantics)
