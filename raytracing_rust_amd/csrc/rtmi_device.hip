@@ -915,28 +915,39 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
         if (((M.flags ^ I.flags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
     }
 
+    // Material::emitted / Material::scatter (material.rs).  The rejection sampler and the texture
+    // lookup are needed by several materials; they are evaluated ONCE here for all lanes that need
+    // them (a per-material copy would run the same long code serially for each lane subset).  The
+    // draw order per lane is unchanged: Lambertian/Isotropic/fuzzy Metal draw only inside the sampler,
+    // Dielectric draws its single uniform, DiffuseLight draws nothing.
     const rtmi_material M = sc.mats[mat_idx];
-    if (M.kind == RTMI_MAT_DIFFUSE_LIGHT) { // material.rs:148-150
-        const F3 e = tex_value(sc, M.tex, hu, hv, hp);
-        pa.L = pa.L + pa.T * e;
-    }
+    const int kind = M.kind;
+    const bool can_scatter = pa.depth < max_depth; // color.rs:9
+    const bool textured = kind == RTMI_MAT_LAMBERTIAN || kind == RTMI_MAT_METAL || kind == RTMI_MAT_ISOTROPIC;
+    const bool want_sample = can_scatter && (kind == RTMI_MAT_LAMBERTIAN || kind == RTMI_MAT_ISOTROPIC ||
+                                             (kind == RTMI_MAT_METAL && M.param > 0.0f));
+    F3 rs = f3(0, 0, 0);
+    if (want_sample) rs = random_in_unit_sphere(g, k0, k1);
+    F3 tv = f3(1, 1, 1);
+    if (kind == RTMI_MAT_DIFFUSE_LIGHT || (can_scatter && textured)) tv = tex_value(sc, M.tex, hu, hv, hp);
+    if (kind == RTMI_MAT_DIFFUSE_LIGHT) pa.L = pa.L + pa.T * tv; // material.rs:148-150
     bool scattered = false;
     const F3 rd = pa.rd;
     F3 nd = rd, att = f3(1, 1, 1);
-    if (pa.depth < max_depth) {
-        if (M.kind == RTMI_MAT_LAMBERTIAN) { // material.rs:49-53 (contract: dir = normal + rand)
-            nd = hn + random_in_unit_sphere(g, k0, k1);
-            att = tex_value(sc, M.tex, hu, hv, hp);
+    if (can_scatter) {
+        if (kind == RTMI_MAT_LAMBERTIAN) { // material.rs:49-53 (contract: dir = normal + rand)
+            nd = hn + rs;
+            att = tv;
             scattered = true;
-        } else if (M.kind == RTMI_MAT_METAL) { // material.rs:75-87
+        } else if (kind == RTMI_MAT_METAL) { // material.rs:75-87
             F3 refl = reflect(normalize(rd), hn);
-            if (M.param > 0.0f) refl = refl + random_in_unit_sphere(g, k0, k1) * M.param;
+            if (M.param > 0.0f) refl = refl + rs * M.param;
             if (dot(refl, hn) > 0.0f) {
                 nd = refl;
-                att = tex_value(sc, M.tex, hu, hv, hp);
+                att = tv;
                 scattered = true;
             }
-        } else if (M.kind == RTMI_MAT_DIELECTRIC) { // material.rs:106-126
+        } else if (kind == RTMI_MAT_DIELECTRIC) { // material.rs:106-126
             F3 outward;
             float ni_over_nt, cosine;
             const float ddn = dot(rd, hn);
@@ -957,9 +968,9 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
             }
             if (!took_refraction) nd = reflect(rd, hn);
             scattered = true;
-        } else if (M.kind == RTMI_MAT_ISOTROPIC) { // material.rs:165-168
-            nd = random_in_unit_sphere(g, k0, k1);
-            att = tex_value(sc, M.tex, hu, hv, hp);
+        } else if (kind == RTMI_MAT_ISOTROPIC) { // material.rs:165-168
+            nd = rs;
+            att = tv;
             scattered = true;
         }
     }
