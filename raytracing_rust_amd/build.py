@@ -22,6 +22,8 @@ HOST_DEPS = HOST_SRC + [os.path.join(_PKG, "host", "rt_host.hpp"), os.path.join(
 
 LIBRTMI = os.path.join(LIB_DIR, "librtmi.so")
 LIBHOST = os.path.join(LIB_DIR, "librt_host.so")
+REFTESTS = os.path.join(LIB_DIR, "rt_reference_tests")  # C++ counterpart of the reference's #[test] drivers
+REFTESTS_SRC = os.path.join(_PKG, "host", "reference_scenes.cpp")
 
 
 def _stale(target, deps):
@@ -52,15 +54,26 @@ def build_host(force=False):
         return LIBHOST
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = ["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall",
-           "-fvisibility=hidden", "-I" + INCLUDE, "-o", LIBHOST] + HOST_SRC + [
+           "-I" + INCLUDE, "-o", LIBHOST] + HOST_SRC + [
                "-L" + LIB_DIR, "-lrtmi", "-Wl,-rpath,$ORIGIN"]
     subprocess.run(cmd, check=True)
     return LIBHOST
 
 
+def build_reference_tests(force=False):
+    if not force and not _stale(REFTESTS, [REFTESTS_SRC, LIBHOST, os.path.join(_PKG, "host", "rt_host.hpp")]):
+        return REFTESTS
+    cmd = ["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17", "-Wall", "-I" + INCLUDE,
+           "-I" + os.path.join(_PKG, "host"), "-o", REFTESTS, REFTESTS_SRC, "-L" + LIB_DIR, "-lrt_host", "-lrtmi",
+           "-Wl,-rpath,$ORIGIN"]
+    subprocess.run(cmd, check=True)
+    return REFTESTS
+
+
 def build_all(force=False, verbose=False):
     build_rtmi(force, verbose)
     build_host(force)
+    build_reference_tests(force)
     return LIBRTMI, LIBHOST
 
 
