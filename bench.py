@@ -50,6 +50,43 @@ def cpu_sample(scene, nx, ny, spp, nrows, seed_scene=1):
     return nrows * nx * spp, dt, counters
 
 
+_ALLCORE = {}
+
+
+def _allcore_init(scene, nx, ny):
+    from oracle.oracle import Oracle
+    from raytracing_rust_amd import scenes
+
+    orc = Oracle("f64")
+    cam, world = scenes.build(orc, scene, nx, ny, seed=1)
+    _ALLCORE.update(orc=orc, cam=cam, world=world, nx=nx, ny=ny)
+
+
+def _allcore_worker(job):
+    spp, rows = job
+    a = _ALLCORE
+    for r in rows:
+        a["orc"].render(a["cam"], a["world"], a["nx"], a["ny"], spp, seed=42, flags=0, rows=(r, r + 1))
+    return len(rows) * a["nx"] * spp
+
+
+def cpu_sample_allcore(scene, nx, ny, spp, rows_per_worker, nproc):
+    """The same oracle on all host cores: `nproc` forked workers (scene built once per worker, not
+    timed), each rendering its own rows (the reference itself is single-threaded; this is the generous
+    baseline of BASELINE.md §3).  Must run BEFORE the process touches the GPU (fork)."""
+    import multiprocessing as mp
+
+    total_rows = rows_per_worker * nproc
+    rows = [int((k + 0.5) * ny / total_rows) for k in range(total_rows)]
+    ctx = mp.get_context("fork")
+    with ctx.Pool(nproc, initializer=_allcore_init, initargs=(scene, nx, ny)) as pool:
+        pool.map(_allcore_worker, [(1, [0])] * nproc)  # every worker has built its scene
+        t0 = time.perf_counter()
+        n = sum(pool.map(_allcore_worker, [(spp, rows[w::nproc]) for w in range(nproc)], chunksize=1))
+        dt = time.perf_counter() - t0
+    return n, dt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +109,18 @@ def main():
                          "fewer GPUs than ranks (ranks share GPUs, the gather goes through host memory)")
     ap.add_argument("--ppm-out", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "rtmi_bench.ppm"))
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    ap.add_argument("--cpu-allcore-procs", type=int, default=min(16, os.cpu_count() or 1),
+                    help="workers of the all-core CPU sample (0 = skip)")
     args = ap.parse_args()
+
+    allcore = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and args.cpu_allcore_procs > 1:
+        # before anything initialises the GPU: the workers are forked
+        spp_all, rows_all = max(1, args.cpu_spp // 4), 8  # many thin rows per worker: balanced
+        n_all, dt_all = cpu_sample_allcore(args.scene, args.nx, args.ny, spp_all, rows_all, args.cpu_allcore_procs)
+        allcore = {"value": round(n_all / dt_all / 1e6, 5), "unit": "Msamples/s", "cores": args.cpu_allcore_procs,
+                   "sample": "%d rows x %d px x %d spp in %d forked workers (%.1f s)"
+                             % (rows_all * args.cpu_allcore_procs, args.nx, spp_all, args.cpu_allcore_procs, dt_all)}
 
     import numpy as np
     import torch
@@ -231,6 +279,7 @@ def main():
             "sample": "%d evenly spaced rows x %d px x %d spp of %s %dx%d (%.1f s, f64 oracle, recursive color)"
                       % (rows, nx, cspp, args.scene, nx, ny, dt_cpu),
             "gpu_over_cpu": round(value / cpu_ms, 1),
+            "all_cores": allcore,
         }
     else:
         out["cpu_baseline"] = None
