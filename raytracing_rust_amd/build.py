@@ -6,6 +6,7 @@
 Flags that matter for parity: -ffp-contract=off on both (no implicit FMA), no fast-math
 (IEEE division/sqrt are correctly rounded by default under hipcc).
 """
+import glob
 import os
 import shutil
 import subprocess
@@ -17,7 +18,8 @@ INCLUDE = os.path.join(_ROOT, "include")
 
 RTMI_SRC = [os.path.join(_PKG, "csrc", "rtmi_device.hip")]
 HOST_SRC = [os.path.join(_PKG, "host", "rt_host.cpp"), os.path.join(_PKG, "host", "rt_host_c.cpp")]
-RTMI_DEPS = RTMI_SRC + [os.path.join(INCLUDE, "rtmi.h"), os.path.join(INCLUDE, "rtmi_math.h")]
+RTMI_DEPS = RTMI_SRC + sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hpp"))) + [
+    os.path.join(INCLUDE, "rtmi.h"), os.path.join(INCLUDE, "rtmi_math.h")]
 HOST_DEPS = HOST_SRC + [os.path.join(_PKG, "host", "rt_host.hpp"), os.path.join(INCLUDE, "rtmi.h")]
 
 LIBRTMI = os.path.join(LIB_DIR, "librtmi.so")

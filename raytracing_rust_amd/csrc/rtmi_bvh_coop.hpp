@@ -1,0 +1,208 @@
+// rtmi_bvh_coop.hpp — wave-cooperative BVH traversal over a shared LDS work pool.
+// Part of the single translation unit rtmi_device.hip (device code is header-only so that every
+// kernel instantiation inlines the whole path); arithmetic contract as stated there.
+#pragma once
+#include "rtmi_bvh.hpp"
+
+// ----------------------------------------------------------------------------------
+// wave-cooperative BVH traversal (FAST semantics; RTMI_FLAG_COOP)
+//
+// Measured with per-lane traversal: only 5-13 % of the lanes are active per traversal iteration
+// — a few rays walk long while the others have left the tree or never entered it.  Here the 64
+// lanes of the wavefront are WORKERS on a wave-shared LIFO of (ray, node) entries in LDS:
+//   * every lane that owns a ray entering the tree publishes its ray context in LDS and pushes
+//     the root; then all 64 lanes, owners or not, pop entries and process them;
+//   * a worker that processed a node keeps the nearer surviving child itself (depth-first, so
+//     its ray context stays in registers) and pushes the farther one for anybody to take;
+//   * a leaf hit is folded into the ray's best hit with ONE LDS atomicMin on the 64-bit key
+//     (order-preserving bits of t, inverted primitive id): minimum t, ties -> the larger
+//     primitive index = the rightmost leaf, exactly the fold of BVHNode::hit (bvh.rs:75-81).
+//     The fold is order-independent, so the result does not depend on who processes what.
+// Pruning is the fast-cull rule (subtree entered later than the ray's best hit + margin);
+// internal boxes are tested against the query's own (t_min, t_max) with the reference's
+// arithmetic.  LIFO order makes workers take the deepest pending entries first, which bounds
+// the pool by 64 * (tree depth + 1) entries; the caller reports an overflow loudly.
+// ----------------------------------------------------------------------------------
+#define COOP_NONE 0xffffffffu
+#define COOP_SENTINEL 0xffffffffffffffffull
+__device__ __forceinline__ uint32_t f2sort(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float sort2f(uint32_t s) {
+    return __uint_as_float((s & 0x80000000u) ? (s & 0x7fffffffu) : ~s);
+}
+// node child reference (rtmi_bvh_node.left/right) -> 26-bit pool encoding
+__device__ __forceinline__ uint32_t coop_enc(int ref) {
+    if (ref >= 0) return (uint32_t)ref;
+    const uint32_t u = (uint32_t)ref;
+    return (1u << 25) | (((u >> 28) & 7u) << 22) | (u & 0x003fffffu);
+}
+
+// All 64 lanes must call this together.  LDS layout for this wave (uint32 words):
+//   pool [cap][2] | ctx [64][12] floats | best [64] uint64
+template <bool PROF>
+__device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, float scale, bool active, const RayF &R,
+                                               float time, float q_min, float q_max, uint32_t *wlds, int cap,
+                                               bool &have, float &t_out, int &pf_out, bool &overflow,
+                                               unsigned long long *prof, int slot) {
+    const int lane = threadIdx.x & 63;
+    volatile uint32_t *pool = wlds;
+    float4 *ctx = reinterpret_cast<float4 *>(wlds + 2 * cap);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(wlds + 2 * cap + 64 * 12);
+
+    const unsigned long long m_act = __ballot(active);
+    have = false;
+    if (m_act == 0ull) return; // wave-uniform: nobody enters this tree
+    // ---- publish ray contexts, push roots
+    best[lane] = COOP_SENTINEL;
+    if (active) {
+        // 48 B per ray; a, inv_a and the pruning margin are recomputed by the worker with the same
+        // operations on the same values (bit-identical), which keeps the wave's LDS under 10 KB
+        ctx[lane * 3 + 0] = make_float4(R.o.x, R.o.y, R.o.z, time);
+        ctx[lane * 3 + 1] = make_float4(R.d.x, R.d.y, R.d.z, q_min);
+        ctx[lane * 3 + 2] = make_float4(R.inv_d.x, R.inv_d.y, R.inv_d.z, q_max);
+        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u));
+        pool[2 * pos] = ((uint32_t)lane << 26) | (uint32_t)root;
+        pool[2 * pos + 1] = __float_as_uint(q_min); // entry distance of the root: conservative
+    }
+    int top = __popcll(m_act);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t cur = COOP_NONE; // 26-bit node/leaf encoding of the entry this worker holds
+    int ray = 0, cray = -1;
+    float tent = 0.0f;
+    RayF W;                   // context of ray `cray`
+    W.o = f3(0, 0, 0); W.d = f3(0, 0, 1); W.inv_d = f3(0, 0, 0); W.a = 1.0f; W.inv_a = 1.0f;
+    float wtime = 0.0f, wqmin = 0.0f, wqmax = 0.0f, wmabs = 0.0f;
+
+    for (;;) {
+        // ---- idle workers take the deepest pending entries
+        const bool needw = cur == COOP_NONE;
+        const unsigned long long m_need = __ballot(needw);
+        const int n_need = __popcll(m_need);
+        if (top == 0 && n_need == 64) break;
+        if (top > cap - 64) { overflow = true; break; }
+        const int take = n_need < top ? n_need : top;
+        if (needw) {
+            const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
+            if (r < take) {
+                const int idx = top - 1 - r;
+                const uint32_t e0 = pool[2 * idx];
+                tent = __uint_as_float(pool[2 * idx + 1]);
+                cur = e0 & 0x03ffffffu;
+                ray = (int)(e0 >> 26);
+            }
+        }
+        top -= take;
+        prof_tick<PROF>(prof, slot, cur != COOP_NONE);
+        bool push = false;
+        uint32_t push_ref = 0u;
+        float push_t = 0.0f;
+        if (cur != COOP_NONE) {
+            if (ray != cray) { // switch ray context
+                const float4 c0 = ctx[ray * 3 + 0], c1 = ctx[ray * 3 + 1], c2 = ctx[ray * 3 + 2];
+                W.o = f3(c0.x, c0.y, c0.z); wtime = c0.w;
+                W.d = f3(c1.x, c1.y, c1.z); wqmin = c1.w;
+                W.inv_d = f3(c2.x, c2.y, c2.z); wqmax = c2.w;
+                W.a = dot(W.d, W.d);
+                W.inv_a = 1.0f / W.a;
+                wmabs = scale * (1.0f / 8192.0f) * __builtin_sqrtf(W.inv_a);
+                cray = ray;
+            }
+            // the ray's best hit so far -> pruning limit
+            const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(&best[ray]);
+            float limit = RTMI_FLT_MAX;
+            if (key != COOP_SENTINEL) {
+                const float bt = sort2f((uint32_t)(key >> 32));
+                limit = bt + (__builtin_fabsf(bt) * (1.0f / 128.0f) + wmabs);
+            }
+            if (tent > limit) {
+                cur = COOP_NONE;
+            } else if (!(cur & (1u << 25))) { // internal node
+                const float4 *n = sc.nodes + (size_t)cur * 4;
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                float tl, tr;
+                bool vl = aabb_hit_t(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, W, wqmin, wqmax, tl);
+                bool vr = aabb_hit_t(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, W, wqmin, wqmax, tr);
+                vl = vl && !(tl > limit);
+                vr = vr && !(tr > limit) && right != left;
+                if (vl && vr) {
+                    const bool lfirst = !(tr < tl);
+                    push = true;
+                    push_ref = coop_enc(lfirst ? right : left);
+                    push_t = lfirst ? tr : tl;
+                    cur = coop_enc(lfirst ? left : right);
+                    tent = lfirst ? tl : tr;
+                } else if (vl) { cur = coop_enc(left); tent = tl; }
+                else if (vr) { cur = coop_enc(right); tent = tr; }
+                else cur = COOP_NONE;
+            } else { // leaf
+                const int type = (int)((cur >> 22) & 7u);
+                const int idx = (int)(cur & 0x003fffffu);
+                float t;
+                int pf;
+                if (prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf)) {
+                    const unsigned long long k = ((unsigned long long)f2sort(t) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)pf);
+                    atomicMin(&best[ray], k);
+                }
+                cur = COOP_NONE;
+            }
+        }
+        // ---- publish the far children
+        const unsigned long long m_push = __ballot(push);
+        if (push) {
+            const int pos = top + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_push >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
+            pool[2 * pos] = ((uint32_t)ray << 26) | push_ref;
+            pool[2 * pos + 1] = __float_as_uint(push_t);
+        }
+        top += __popcll(m_push);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (active) {
+        const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(&best[lane]);
+        if (key != COOP_SENTINEL) {
+            have = true;
+            t_out = sort2f((uint32_t)(key >> 32));
+            pf_out = (int)(0x7fffffffu - (uint32_t)key);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// geometry of one item for the whole wavefront: every lane calls it; `active` lanes own a query
+template <bool PROF>
+__device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_item &I, bool active, const RayF &r,
+                                                float time, float q_min, float q_max, uint32_t *wlds, int cap,
+                                                float &t_out, int &pf_out, bool &overflow, unsigned long long *prof,
+                                                int slot) {
+    if (I.kind == RTMI_ITEM_BVH) { // wave-uniform branch
+        // BVHNode::hit of the root: its own bbox first (bvh.rs:71)
+        const bool enter = active && aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
+                                              I.root_max[2], r, q_min, q_max);
+        bool have = false;
+        coop_bvh_query<PROF>(sc, I.first, I.scale, enter, r, time, q_min, q_max, wlds, cap, have, t_out, pf_out, overflow,
+                             prof, slot);
+        return have;
+    }
+    // HittableList::hit — hittable.rs:37-47
+    float cl = q_max;
+    bool any = false;
+    if (active) {
+        for (int k = 0; k < I.count; k++) {
+            const int idx = I.first + k;
+            const int type = sc.meta[idx].type;
+            float t;
+            int pf;
+            prof_tick<PROF>(prof, 13, true);
+            if (prim_test(sc, type, idx, r, time, q_min, cl, t, pf)) { cl = t; any = true; pf_out = pf; }
+        }
+    }
+    t_out = cl;
+    return any;
+}

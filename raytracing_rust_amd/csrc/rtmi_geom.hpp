@@ -1,0 +1,162 @@
+// rtmi_geom.hpp — instance transforms, the per-frame ray, box / sphere / rect / cube tests.
+// Part of the single translation unit rtmi_device.hip (device code is header-only so that every
+// kernel instantiation inlines the whole path); arithmetic contract as stated there.
+#pragma once
+#include "rtmi_types.hpp"
+
+// ----------------------------------------------------------------------------------
+// instance transforms — src/traslate.rs:18-24, src/rotate.rs:85-113
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ void rot_fwd(float s, float c, float &a, float &b) {
+    float na = c * a + s * b;
+    float nb = -s * a + c * b;
+    a = na; b = nb;
+}
+__device__ __forceinline__ void rot_inv(float s, float c, float &a, float &b) {
+    float na = c * a - s * b;
+    float nb = s * a + c * b;
+    a = na; b = nb;
+}
+// world -> object; returns true when the direction changed (a rotation was applied)
+__device__ __forceinline__ bool xform_ray(const rtmi_xform *xf, int first, int count, F3 &o, F3 &d) {
+    bool rotated = false;
+    for (int k = 0; k < count; k++) {
+        const rtmi_xform X = xf[first + k];
+        switch (X.kind) {
+        case RTMI_XF_TRANSLATE: o = o - f3(X.x, X.y, X.z); break;
+        case RTMI_XF_ROTATE_X: rot_fwd(X.x, X.y, o.y, o.z); rot_fwd(X.x, X.y, d.y, d.z); rotated = true; break;
+        case RTMI_XF_ROTATE_Y: rot_fwd(X.x, X.y, o.z, o.x); rot_fwd(X.x, X.y, d.z, d.x); rotated = true; break;
+        default: rot_fwd(X.x, X.y, o.x, o.y); rot_fwd(X.x, X.y, d.x, d.y); rotated = true; break;
+        }
+    }
+    return rotated;
+}
+// object -> world for the hit point and normal (innermost wrapper first)
+__device__ __forceinline__ void xform_hit(const rtmi_xform *xf, int first, int count, F3 &p, F3 &n) {
+    for (int k = count - 1; k >= 0; k--) {
+        const rtmi_xform X = xf[first + k];
+        switch (X.kind) {
+        case RTMI_XF_TRANSLATE: p = p + f3(X.x, X.y, X.z); break;
+        case RTMI_XF_ROTATE_X: rot_inv(X.x, X.y, p.y, p.z); rot_inv(X.x, X.y, n.y, n.z); break;
+        case RTMI_XF_ROTATE_Y: rot_inv(X.x, X.y, p.z, p.x); rot_inv(X.x, X.y, n.z, n.x); break;
+        default: rot_inv(X.x, X.y, p.x, p.y); rot_inv(X.x, X.y, n.x, n.y); break;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// intersectors
+// ----------------------------------------------------------------------------------
+struct RayF { // a ray in one frame, with the per-frame derived values
+    F3 o, d, inv_d;
+    float a, inv_a; // d.d and 1/(d.d)  (sphere.rs:40, contract: t = (-b -+ sqrt)*inv_a)
+};
+__device__ __forceinline__ void ray_derive(RayF &r) {
+    r.inv_d = f3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z); // aabb.rs:33
+    r.a = dot(r.d, r.d);
+    r.inv_a = 1.0f / r.a;
+}
+
+// AABB::hit — src/aabb.rs:31-44.  The sequential early-out is an OR of the three tests.
+__device__ __forceinline__ bool aabb_hit(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
+                                         const RayF &r, float t_min, float t_max) {
+    float t0 = (mnx - r.o.x) * r.inv_d.x, t1 = (mxx - r.o.x) * r.inv_d.x;
+    bool neg = r.inv_d.x < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    bool fail = t_max <= t_min;
+    t0 = (mny - r.o.y) * r.inv_d.y; t1 = (mxy - r.o.y) * r.inv_d.y;
+    neg = r.inv_d.y < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    fail |= t_max <= t_min;
+    t0 = (mnz - r.o.z) * r.inv_d.z; t1 = (mxz - r.o.z) * r.inv_d.z;
+    neg = r.inv_d.z < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    fail |= t_max <= t_min;
+    return !fail;
+}
+
+// Sphere::hit / MovingSphere::hit — src/sphere.rs:37-77, 122-164 (t only; the record is
+// built once for the closest hit in finalize_hit)
+__device__ __forceinline__ bool sphere_test(const RayF &r, F3 c, float radius, float t_min, float t_max, float &t_out) {
+    F3 oc = r.o - c;
+    float b = dot(oc, r.d);
+    float cc = dot(oc, oc) - radius * radius;
+    float disc = b * b - r.a * cc;
+    if (disc > 0.0f) {
+        float sq = __builtin_sqrtf(disc);
+        float t = (-b - sq) * r.inv_a;
+        if (t < t_max && t > t_min) { t_out = t; return true; }
+        t = (-b + sq) * r.inv_a;
+        if (t < t_max && t > t_min) { t_out = t; return true; }
+    }
+    return false;
+}
+// MovingSphere::center — src/sphere.rs:115-118 (contract: (time - t0) * inv_dt)
+__device__ __forceinline__ F3 moving_center(float4 A, float4 B, float inv_dt, float time) {
+    float f = (time - B.w) * inv_dt;
+    return f3(A.x, A.y, A.z) + f3(B.x, B.y, B.z) * f;
+}
+
+// Rect::hit — src/rect.rs:39-69 with (k,a,b) = YZ:(0,1,2) ZX:(1,2,0) XY:(2,0,1)
+template <int P>
+__device__ __forceinline__ bool rect_test(float x0, float y0, float x1, float y1, float k, const RayF &r, float t_min,
+                                          float t_max, float &t_out) {
+    constexpr int K = P == 0 ? 0 : (P == 1 ? 1 : 2);
+    constexpr int A = P == 0 ? 1 : (P == 1 ? 2 : 0);
+    constexpr int B = P == 0 ? 2 : (P == 1 ? 0 : 1);
+    float t = (k - comp<K>(r.o)) * comp<K>(r.inv_d);
+    if (t < t_min || t > t_max) return false;
+    float x = comp<A>(r.o) + t * comp<A>(r.d);
+    float y = comp<B>(r.o) + t * comp<B>(r.d);
+    if (x < x0 || x > x1 || y < y0 || y > y1) return false;
+    t_out = t;
+    return true;
+}
+__device__ __forceinline__ bool rect_test_rt(int plane, float4 A, float k, const RayF &r, float t_min, float t_max,
+                                             float &t_out) {
+    if (plane == 0) return rect_test<0>(A.x, A.y, A.z, A.w, k, r, t_min, t_max, t_out);
+    if (plane == 1) return rect_test<1>(A.x, A.y, A.z, A.w, k, r, t_min, t_max, t_out);
+    return rect_test<2>(A.x, A.y, A.z, A.w, k, r, t_min, t_max, t_out);
+}
+// Cube::hit — src/cube.rs:84-86: HittableList scan (hittable.rs:37-47) of the six rects in
+// construction order (cube.rs:21-74); a later face wins a tie because Rect accepts t == t_max.
+__device__ __forceinline__ bool cube_test(float4 A, float4 B, const RayF &r, float t_min, float t_max, float &t_out,
+                                          int &face) {
+    const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
+    float cl = t_max, t;
+    bool any = false;
+    if (rect_test<2>(ax, ay, bx, by, bz, r, t_min, cl, t)) { cl = t; any = true; face = 0; }
+    if (rect_test<2>(ax, ay, bx, by, az, r, t_min, cl, t)) { cl = t; any = true; face = 1; }
+    if (rect_test<1>(az, ax, bz, bx, by, r, t_min, cl, t)) { cl = t; any = true; face = 2; }
+    if (rect_test<1>(az, ax, bz, bx, ay, r, t_min, cl, t)) { cl = t; any = true; face = 3; }
+    if (rect_test<0>(ay, az, by, bz, bx, r, t_min, cl, t)) { cl = t; any = true; face = 4; }
+    if (rect_test<0>(ay, az, by, bz, ax, r, t_min, cl, t)) { cl = t; any = true; face = 5; }
+    t_out = cl;
+    return any;
+}
+
+// one primitive against (t_min, t_max); pf = prim << 3 | face.  The three planes are loaded up
+// front (independent addresses): one memory latency instead of up to three dependent ones.
+__device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx, const RayF &r, float time,
+                                          float t_min, float t_max, float &t_out, int &pf) {
+    const float4 A = sc.prim_a[idx];
+    const float4 B = sc.prim_b[idx];
+    const rtmi_prim_meta M = sc.meta[idx];
+    bool h = false;
+    int face = 0;
+    if (type == RTMI_PRIM_SPHERE) {
+        h = sphere_test(r, f3(A.x, A.y, A.z), A.w, t_min, t_max, t_out);
+    } else if (type == RTMI_PRIM_MSPHERE) {
+        h = sphere_test(r, moving_center(A, B, M.inv_dt, time), A.w, t_min, t_max, t_out);
+    } else if (type == RTMI_PRIM_RECT) {
+        const int plane = (int)((M.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
+        h = rect_test_rt(plane, A, B.x, r, t_min, t_max, t_out);
+    } else {
+        h = cube_test(A, B, r, t_min, t_max, t_out, face);
+    }
+    pf = (idx << 3) | face;
+    return h;
+}

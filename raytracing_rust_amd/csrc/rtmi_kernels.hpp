@@ -1,0 +1,558 @@
+// rtmi_kernels.hpp — render kernels (per-lane two-phase, wave-cooperative, async state machine), resolve, probes.
+// Part of the single translation unit rtmi_device.hip (device code is header-only so that every
+// kernel instantiation inlines the whole path); arithmetic contract as stated there.
+#pragma once
+#include "rtmi_bvh_coop.hpp"
+#include "rtmi_shade.hpp"
+
+// ----------------------------------------------------------------------------------
+// render kernel, two-phase form (RTMI_FLAG_SYNC): the wavefront alternates between
+//   phase A  every lane that holds no unshaded hit traces: (next camera sample if its path ended)
+//            + world.hit(); a lane whose ray misses immediately starts its next sample and traces
+//            again, while lanes that already found a hit wait.  The phase ends when at least
+//            `P.shade_threshold` lanes hold a hit (or no lane can produce one any more).
+//   phase B  all lanes holding a hit build the hit record and run the material.
+// Shading (Perlin turbulence, rejection samplers, Philox refills, ...) is expensive and very
+// divergent; batching it until most lanes need it runs it at high lane utilisation, at the
+// price of a few partially filled tracing rounds.  Per-lane program order is unchanged, so
+// results do not depend on the threshold.
+// ----------------------------------------------------------------------------------
+template <bool FAST, bool SIG, bool PROF>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevScene sc, DevCamera cam, DevParams P,
+                                                                           double *__restrict__ partial) {
+    __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
+    unsigned long long *prof = prof_lds;
+    if (PROF) {
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS) prof_lds[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
+    // per wave: [0] node refs, [1] entry distances (FAST only); entry-major so lanes never bank-conflict
+    __shared__ uint32_t lds_stack[WAVES_PER_BLOCK][FAST ? 2 : 1][RTMI_MAX_BVH_DEPTH][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    uint32_t *stack = &lds_stack[wave][0][0][lane];
+    unsigned long long sig = 0ull;
+    const LaneJob J = lane_job(P, wave, lane);
+    if (!PROF && !J.wave_has_work) return;
+    const uint32_t k0 = P.key0, k1 = P.key1;
+    const int threshold = (int)P.shade_threshold;
+
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0; // `col += color(..)` — tests/test.rs:69 (f64 like the reference)
+    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
+    bool alive = false, done = s >= J.s_end, have_hit = false;
+    Rng g;
+    rng_init(g, 0, 0);
+    Path pa;
+    pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
+    float closest = RTMI_FLT_MAX;
+    int best_item = -1, best_pf = 0;
+    bool best_medium = false;
+
+    for (;;) {
+        // ================= phase A: trace until enough lanes hold a hit =================
+        for (;;) {
+            const bool need = !have_hit && !done;
+            if (__ballot(need) == 0ull) break;
+            prof_tick<PROF>(prof, 0, need);
+            if (need) {
+                if (!alive) {
+                    camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
+                    alive = true;
+                }
+                // ---- world.hit(ray, 0.001, f64::MAX): scan of the top-level list (hittable.rs:37-47)
+                RayF W;
+                W.o = pa.ro; W.d = pa.rd;
+                ray_derive(W);
+                closest = RTMI_FLT_MAX;
+                best_item = -1; best_pf = 0; best_medium = false;
+                for (uint32_t it = 0; it < sc.n_items; it++) {
+                    const rtmi_item I = sc.items[it];
+                    RayF R = W;
+                    if (I.xform_count > 0) {
+                        if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
+                    }
+                    const int slot = 1 + (it < 11u ? (int)it : 11);
+                    if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
+                        float t;
+                        int pf;
+                        if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, P.t_min, closest, stack, t, pf, prof, slot)) {
+                            closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
+                        }
+                    } else {
+                        // ConstantMedium::hit — medium.rs:28-56
+                        float t1, t2, tm;
+                        int pf;
+                        if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, stack, t1, pf, prof, slot)) {
+                            if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, stack, t2, pf, prof, slot)) {
+                                if (medium_sample(t1, t2, P.t_min, closest, W.d, I.neg_inv_density, g, k0, k1, tm)) {
+                                    closest = tm; best_item = (int)it; best_medium = true;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (best_item >= 0) {
+                    have_hit = true;
+                } else { // miss: black background (color.rs:21); the path ends, next sample
+                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                    s++; alive = false;
+                    done = s >= J.s_end;
+                }
+            }
+            if (__popcll(__ballot(have_hit)) >= threshold) break;
+        }
+        // ================= phase B: shade every lane that holds a hit =================
+        if (__ballot(have_hit) == 0ull) break; // nobody holds a hit and nobody can trace: all done
+        prof_tick<PROF>(prof, 16, have_hit);
+        if (have_hit) {
+            have_hit = false;
+            if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+            if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+                // absorbed, emitter or depth limit: the path ends
+                acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                s++; alive = false;
+                done = s >= J.s_end;
+            }
+        }
+    }
+
+    if (PROF) {
+        __syncthreads();
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
+        if (!J.wave_has_work) return;
+    }
+    // partial[chunk][ltile][channel][lane]
+    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
+    out[0] = acc0; out[64] = acc1; out[128] = acc2;
+    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig); // integer add: order-independent
+}
+
+// ----------------------------------------------------------------------------------
+// render kernel, two-phase form with wave-cooperative BVH traversal (default).
+// Same schedule as rtmi_render_kernel; the item scan of phase A is executed by ALL lanes (lanes
+// without a pending query are workers for the others' BVH traversals).
+// ----------------------------------------------------------------------------------
+template <bool SIG, bool PROF, int WPS>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(DevScene sc, DevCamera cam, DevParams P,
+                                                                              double *__restrict__ partial) {
+    __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
+    unsigned long long *prof = prof_lds;
+    if (PROF) {
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS) prof_lds[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; // per wave: pool | ctx | best
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int cap = (int)P.coop_cap;
+    uint32_t *wlds = lds_dyn + (size_t)wave * (2u * cap + 64u * 12u + 128u);
+    unsigned long long sig = 0ull;
+    const LaneJob J = lane_job(P, wave, lane);
+    if (!PROF && !J.wave_has_work) return;
+    const uint32_t k0 = P.key0, k1 = P.key1;
+    const int threshold = (int)P.shade_threshold;
+
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
+    bool alive = false, done = s >= J.s_end, have_hit = false, overflow = false;
+    Rng g;
+    rng_init(g, 0, 0);
+    Path pa;
+    pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
+    float closest = RTMI_FLT_MAX;
+    int best_item = -1, best_pf = 0;
+    bool best_medium = false;
+    unsigned long long tstamp = PROF ? __builtin_readcyclecounter() : 0ull;
+
+    for (;;) {
+        // ================= phase A =================
+        for (;;) {
+            const bool need = !have_hit && !done;
+            if (__ballot(need) == 0ull) break;
+            prof_tick<PROF>(prof, 0, need);
+            prof_time<PROF>(prof, 31, tstamp); // loop overhead / phase switching
+            if (need && !alive) {
+                camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
+                alive = true;
+            }
+            prof_time<PROF>(prof, 25, tstamp); // camera samples
+            RayF W;
+            W.o = pa.ro; W.d = pa.rd;
+            ray_derive(W);
+            if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
+            for (uint32_t it = 0; it < sc.n_items; it++) { // executed by all 64 lanes
+                const rtmi_item I = sc.items[it];
+                RayF R = W;
+                if (I.xform_count > 0) {
+                    if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
+                }
+                const int slot = 1 + (it < 11u ? (int)it : 11);
+                if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
+                    float t;
+                    int pf;
+                    if (geom_query_coop<PROF>(sc, I, need, R, pa.rtime, P.t_min, closest, wlds, cap, t, pf, overflow, prof, slot)) {
+                        closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
+                    }
+                    prof_time<PROF>(prof, I.kind == RTMI_ITEM_BVH ? (it == 0 ? 27 : 28) : 26, tstamp);
+                } else {
+                    // ConstantMedium::hit — medium.rs:28-56
+                    float t1 = 0.0f, t2 = 0.0f, tm;
+                    int pf;
+                    const bool h1 = geom_query_coop<PROF>(sc, I, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, wlds, cap, t1, pf, overflow, prof, slot);
+                    const bool h2 = geom_query_coop<PROF>(sc, I, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, wlds, cap, t2, pf, overflow, prof, slot);
+                    if (need && h1 && h2) {
+                        if (medium_sample(t1, t2, P.t_min, closest, W.d, I.neg_inv_density, g, k0, k1, tm)) {
+                            closest = tm; best_item = (int)it; best_medium = true;
+                        }
+                    }
+                    prof_time<PROF>(prof, 29, tstamp); // media
+                }
+            }
+            if (need) {
+                if (best_item >= 0) {
+                    have_hit = true;
+                } else { // miss: black background (color.rs:21)
+                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                    s++; alive = false;
+                    done = s >= J.s_end;
+                }
+            }
+            if (__popcll(__ballot(have_hit)) >= threshold) break;
+        }
+        // ================= phase B =================
+        if (__ballot(have_hit) == 0ull) break;
+        prof_tick<PROF>(prof, 16, have_hit);
+        if (have_hit) {
+            have_hit = false;
+            if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+            if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+                acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                s++; alive = false;
+                done = s >= J.s_end;
+            }
+        }
+        prof_time<PROF>(prof, 30, tstamp); // shading
+    }
+    if (__ballot(overflow) != 0ull && lane == 0) atomicAdd(P.status, 1u); // reported loudly by the host
+
+    if (PROF) {
+        __syncthreads();
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
+        if (!J.wave_has_work) return;
+    }
+    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
+    out[0] = acc0; out[64] = acc1; out[128] = acc2;
+    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig);
+}
+
+// ----------------------------------------------------------------------------------
+// render kernel, asynchronous form (default).
+//
+// Measured on the synchronous kernel: inside BVH traversal only 4-10 % of the lanes are active
+// per iteration (a few lanes walk long while the rest have already left the tree), because the
+// whole wavefront waits at every item and at every bounce.  Here every lane is its own state
+// machine over the SAME per-lane program order (items in list order, media draws in order, so
+// results are bit-identical): a lane that finished its hit query goes on to shade, to its next
+// bounce and to its next sample while others still traverse.  Each loop iteration the wavefront
+// VOTES (ballots) for the state most lanes are in and executes only that body, which lets lanes
+// that drifted apart re-converge; lanes in other states wait one round.
+//   ST_ITEM : commit the finished item into `closest` (incl. ConstantMedium logic), then enter
+//             following items; single-primitive items are tested right here
+//   ST_NODE : one BVH node step        ST_PRIM : one primitive (BVH leaf or nested-list member)
+//   ST_SHADE: hit record + material    ST_NEW  : next camera sample      ST_DONE
+// ----------------------------------------------------------------------------------
+enum { ST_ITEM = 0, ST_NODE = 1, ST_PRIM = 2, ST_SHADE = 3, ST_NEW = 4, ST_DONE = 5 };
+
+template <bool FAST, bool SIG, bool PROF>
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevScene sc, DevCamera cam, DevParams P,
+                                                                          double *__restrict__ partial) {
+    __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
+    unsigned long long *prof = prof_lds;
+    if (PROF) {
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS) prof_lds[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; // [wave][2][stack_depth][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint32_t SD = P.stack_depth;
+    uint32_t *stack = lds_dyn + (size_t)wave * 2u * SD * 64u + lane;
+    float *stack_t = reinterpret_cast<float *>(stack + SD * 64u);
+    unsigned long long sig = 0ull;
+    const LaneJob J = lane_job(P, wave, lane);
+    if (!PROF && !J.wave_has_work) return;
+    const uint32_t k0 = P.key0, k1 = P.key1;
+    const int n_items = (int)sc.n_items;
+
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
+    Rng g;
+    rng_init(g, 0, 0);
+    Path pa;
+    pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
+
+    // hit-query state
+    RayF W;             // world-frame ray of the current query
+    W.o = pa.ro; W.d = pa.rd; W.inv_d = f3(0, 0, 0); W.a = 1.0f; W.inv_a = 1.0f;
+    RayF R = W;         // ray in the frame of the current item
+    int it = 0, ph = 0; // item index, ConstantMedium phase (0: first boundary query, 1: second)
+    bool pending = false;           // item `it` has finished with (have, bt, bpf) and must be committed
+    float closest = RTMI_FLT_MAX, t1 = 0.0f;
+    int best_item = -1, best_pf = 0;
+    bool best_medium = false;
+    uint32_t iflags = 0u;
+    float q_min = 0.0f, q_max = 0.0f;
+    // traversal / list state of the current item
+    int cur = 0, sp = 0, pend = 0;  // node-or-leaf ref | list cursor, stack pointer, list end
+    bool have = false, is_list = false;
+    float bt = 0.0f, limit = RTMI_FLT_MAX, m_abs = 0.0f;
+    int bpf = 0;
+    int st = ST_NEW;
+
+    for (;;) {
+        // ---- vote
+        const unsigned long long mI = __ballot(st == ST_ITEM), mN = __ballot(st == ST_NODE), mP = __ballot(st == ST_PRIM),
+                                 mS = __ballot(st == ST_SHADE), mC = __ballot(st == ST_NEW);
+        const int nI = __popcll(mI), nN = __popcll(mN), nP = __popcll(mP), nS = __popcll(mS), nC = __popcll(mC);
+        if ((nI | nN | nP | nS | nC) == 0) break; // every lane is ST_DONE
+        int run = ST_ITEM, best_n = nI;
+        if (nN > best_n) { run = ST_NODE; best_n = nN; }
+        if (nP > best_n) { run = ST_PRIM; best_n = nP; }
+        if (nS > best_n) { run = ST_SHADE; best_n = nS; }
+        if (nC > best_n) { run = ST_NEW; best_n = nC; }
+        prof_tick<PROF>(prof, 20 + run, st == run);
+
+        if (run == ST_NODE) {
+            if (st == ST_NODE) {
+                const float4 *n = sc.nodes + (size_t)cur * 4;
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                int next = 0;
+                bool got = false;
+                if (!FAST) {
+                    bool vl = left < 0 || aabb_hit(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, R, q_min, q_max);
+                    bool vr = right < 0 || aabb_hit(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, R, q_min, q_max);
+                    if (right == left) vr = false;
+                    if (vl) {
+                        if (vr) { stack[sp * 64] = (uint32_t)right; sp++; }
+                        next = left; got = true;
+                    } else if (vr) { next = right; got = true; }
+                    if (!got && sp > 0) { sp--; next = (int)stack[sp * 64]; got = true; }
+                } else {
+                    float tl, tr;
+                    bool vl = aabb_hit_t(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, R, q_min, q_max, tl);
+                    bool vr = aabb_hit_t(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, R, q_min, q_max, tr);
+                    vl = vl && !(tl > limit);
+                    vr = vr && !(tr > limit) && right != left;
+                    if (vl && vr) {
+                        const bool lfirst = !(tr < tl);
+                        stack[sp * 64] = (uint32_t)(lfirst ? right : left);
+                        stack_t[sp * 64] = lfirst ? tr : tl;
+                        sp++;
+                        next = lfirst ? left : right; got = true;
+                    } else if (vl) { next = left; got = true; }
+                    else if (vr) { next = right; got = true; }
+                    while (!got && sp > 0) {
+                        sp--;
+                        if (!(stack_t[sp * 64] > limit)) { next = (int)stack[sp * 64]; got = true; }
+                    }
+                }
+                if (got) { cur = next; st = next >= 0 ? ST_NODE : ST_PRIM; }
+                else { pending = true; st = ST_ITEM; }
+            }
+        } else if (run == ST_PRIM) {
+            if (st == ST_PRIM) {
+                float t;
+                int pf;
+                if (is_list) { // HittableList::hit — hittable.rs:37-47 (nested list of primitives)
+                    const int type = sc.meta[cur].type;
+                    if (prim_test(sc, type, cur, R, pa.rtime, q_min, bt, t, pf)) { bt = t; bpf = pf; have = true; }
+                    cur++;
+                    if (cur >= pend) { pending = true; st = ST_ITEM; }
+                } else {       // BVH leaf
+                    const int type = (int)(((uint32_t)cur >> 28) & 7u);
+                    const int idx = (int)((uint32_t)cur & 0x0fffffffu);
+                    if (prim_test(sc, type, idx, R, pa.rtime, q_min, q_max, t, pf)) {
+                        if (!FAST) {
+                            if (!have || !(bt < t)) { bt = t; bpf = pf; have = true; }
+                        } else if (!have || t < bt || (t == bt && pf > bpf)) {
+                            bt = t; bpf = pf; have = true;
+                            limit = bt + (__builtin_fabsf(bt) * (1.0f / 128.0f) + m_abs);
+                        }
+                    }
+                    bool got = false;
+                    int next = 0;
+                    if (!FAST) {
+                        if (sp > 0) { sp--; next = (int)stack[sp * 64]; got = true; }
+                    } else {
+                        while (!got && sp > 0) {
+                            sp--;
+                            if (!(stack_t[sp * 64] > limit)) { next = (int)stack[sp * 64]; got = true; }
+                        }
+                    }
+                    if (got) { cur = next; st = next >= 0 ? ST_NODE : ST_PRIM; }
+                    else { pending = true; st = ST_ITEM; }
+                }
+            }
+        } else if (run == ST_ITEM) {
+            if (st == ST_ITEM) {
+                for (;;) {
+                    // ---- commit the finished item (hittable.rs:40-45; medium.rs:30-53)
+                    if (pending) {
+                        pending = false;
+                        if (!(iflags & RTMI_ITEMFLAG_MEDIUM)) {
+                            if (have) { closest = bt; best_item = it; best_pf = bpf; best_medium = false; }
+                            it++;
+                        } else if (ph == 0) {
+                            if (have) { t1 = bt; ph = 1; } else { it++; }
+                        } else {
+                            if (have) {
+                                float tm;
+                                if (medium_sample(t1, bt, P.t_min, closest, W.d, sc.items[it].neg_inv_density, g, k0, k1, tm)) {
+                                    closest = tm; best_item = it; best_medium = true;
+                                }
+                            }
+                            ph = 0;
+                            it++;
+                        }
+                    }
+                    // ---- end of the list: world.hit() is complete (color.rs:7)
+                    if (it >= n_items) {
+                        if (best_item >= 0) { st = ST_SHADE; }
+                        else { // miss: black background (color.rs:21)
+                            acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                            s++; st = ST_NEW;
+                        }
+                        break;
+                    }
+                    // ---- enter item `it`
+                    const rtmi_item I = sc.items[it];
+                    iflags = I.flags;
+                    R = W;
+                    if (I.xform_count > 0) {
+                        if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
+                    }
+                    if (iflags & RTMI_ITEMFLAG_MEDIUM) {
+                        q_min = ph == 0 ? -RTMI_FLT_MAX : t1 + 0.0001f;
+                        q_max = RTMI_FLT_MAX;
+                    } else {
+                        q_min = P.t_min;
+                        q_max = closest;
+                    }
+                    have = false;
+                    if (I.kind == RTMI_ITEM_BVH) {
+                        // BVHNode::hit of the root: its own bbox first (bvh.rs:71)
+                        if (!aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
+                                      I.root_max[2], R, q_min, q_max)) {
+                            pending = true;
+                            continue;
+                        }
+                        cur = I.first; sp = 0; is_list = false;
+                        bt = FAST ? RTMI_FLT_MAX : 0.0f; bpf = 0; limit = RTMI_FLT_MAX;
+                        m_abs = FAST ? I.scale * (1.0f / 8192.0f) * __builtin_sqrtf(R.inv_a) : 0.0f;
+                        st = ST_NODE;
+                        break;
+                    }
+                    if (I.count == 1) { // a single primitive: test it here
+                        float t;
+                        int pf;
+                        const int type = sc.meta[I.first].type;
+                        if (prim_test(sc, type, I.first, R, pa.rtime, q_min, q_max, t, pf)) { bt = t; bpf = pf; have = true; }
+                        pending = true;
+                        continue;
+                    }
+                    if (I.count <= 0) { pending = true; continue; }
+                    cur = I.first; pend = I.first + I.count; is_list = true; bt = q_max; bpf = 0;
+                    st = ST_PRIM;
+                    break;
+                }
+            }
+        } else if (run == ST_SHADE) {
+            if (st == ST_SHADE) {
+                if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+                if (shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+                    W.o = pa.ro; W.d = pa.rd;
+                    ray_derive(W);
+                    it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;
+                    st = ST_ITEM;
+                } else {
+                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                    s++; st = ST_NEW;
+                }
+            }
+        } else { // ST_NEW
+            if (st == ST_NEW) {
+                if (s >= J.s_end) { st = ST_DONE; }
+                else {
+                    camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
+                    W.o = pa.ro; W.d = pa.rd;
+                    ray_derive(W);
+                    it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;
+                    st = ST_ITEM;
+                }
+            }
+        }
+    }
+
+    if (PROF) {
+        __syncthreads();
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
+        if (!J.wave_has_work) return;
+    }
+    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
+    out[0] = acc0; out[64] = acc1; out[128] = acc2;
+    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig);
+}
+
+// `col /= ns; sqrt; clamp; (255.99*c) as i32` — tests/test.rs:71-78, per local texel.
+// Chunk partial sums are added in chunk order (deterministic).
+__global__ void rtmi_resolve_kernel(const double *__restrict__ partial, rtmi_texel *__restrict__ out, DevParams P) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= P.ntiles_local * 64u) return;
+    const uint32_t ltile = tid >> 6, lane = tid & 63u;
+    double sum[3] = {0.0, 0.0, 0.0};
+    for (uint32_t c = 0; c < P.nchunks; c++) {
+        const double *src = partial + ((size_t)(c * P.ntiles_local + ltile) * 3) * 64 + lane;
+        sum[0] += src[0]; sum[1] += src[64]; sum[2] += src[128];
+    }
+    rtmi_texel tx;
+    uint32_t q[3];
+    float lin[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const double m = sum[ch] / (double)P.ns;
+        lin[ch] = (float)m;
+        double g = sqrt(m);
+        g = (g > 0.0) ? ((g < 1.0) ? g : 1.0) : 0.0; // nalgebra::clamp(val, 0, 1); NaN -> 0
+        const double x = 255.99 * g;
+        q[ch] = (x != x) ? 0u : (uint32_t)(int32_t)x; // `as i32`; in [0,255] after the clamp
+    }
+    tx.r = lin[0]; tx.g = lin[1]; tx.b = lin[2];
+    tx.rgb8 = q[0] | (q[1] << 8) | (q[2] << 16);
+    out[tid] = tx;
+}
+
+// ---- device evaluation of the arithmetic contract, for parity tests --------------------
+// op: 0 sin, 1 log, 2 atan2(x,y), 3 asin, 4 x/y, 5 sqrt, 6 u01(bits of x)
+__global__ void rtmi_math_probe_kernel(int op, const float *x, const float *y, float *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r;
+    switch (op) {
+    case 0: r = rtmi_sinf(x[i]); break;
+    case 1: r = rtmi_logf(x[i]); break;
+    case 2: r = rtmi_atan2f(x[i], y[i]); break;
+    case 3: r = rtmi_asinf(x[i]); break;
+    case 4: r = x[i] / y[i]; break;
+    case 5: r = __builtin_sqrtf(x[i]); break;
+    default: r = rtmi_u01(__float_as_uint(x[i])); break;
+    }
+    out[i] = r;
+}
+__global__ void rtmi_philox_probe_kernel(const uint32_t *ctr, const uint32_t *key, uint32_t *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t o0, o1, o2, o3;
+    philox(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[2 * i], key[2 * i + 1], o0, o1, o2, o3);
+    out[4 * i] = o0; out[4 * i + 1] = o1; out[4 * i + 2] = o2; out[4 * i + 3] = o3;
+}

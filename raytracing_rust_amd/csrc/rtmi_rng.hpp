@@ -1,0 +1,92 @@
+// rtmi_rng.hpp — Philox4x32-10 counter streams and the rejection samplers.
+// Part of the single translation unit rtmi_device.hip (device code is header-only so that every
+// kernel instantiation inlines the whole path); arithmetic contract as stated there.
+#pragma once
+#include "rtmi_types.hpp"
+
+// ----------------------------------------------------------------------------------
+// Philox4x32-10; stream = (block, sample, pixel, 0) under key = seed
+// ----------------------------------------------------------------------------------
+struct Rng {
+    uint32_t block, sample, pixel;
+    uint32_t b0, b1, b2, b3;
+    uint32_t pos;
+};
+__device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                       uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+__device__ __forceinline__ void rng_init(Rng &g, uint32_t sample, uint32_t pixel) {
+    g.block = 0; g.sample = sample; g.pixel = pixel; g.pos = 4;
+}
+// rng.gen::<f64>() of the reference (24-bit uniform, rtmi_u01)
+__device__ __forceinline__ float rng_uniform(Rng &g, uint32_t k0, uint32_t k1) {
+    if (g.pos == 4) {
+        philox(g.block, g.sample, g.pixel, 0u, k0, k1, g.b0, g.b1, g.b2, g.b3);
+        g.block++;
+        g.pos = 0;
+    }
+    uint32_t w = g.pos == 0 ? g.b0 : (g.pos == 1 ? g.b1 : (g.pos == 2 ? g.b2 : g.b3));
+    g.pos++;
+    return rtmi_u01(w);
+}
+
+// The next THREE (resp. TWO) consecutive words of the stream with at most ONE Philox evaluation
+// for the whole wavefront.  Calling rng_uniform three times evaluates Philox up to three times per
+// wavefront (lanes sit at different positions of their 4-word blocks, so at every call some lane
+// needs a refill and the others wait).  Same stream, same words, same order: bit-identical.
+__device__ __forceinline__ void rng_take3(Rng &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+    uint32_t n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
+    const uint32_t pos = g.pos;
+    if (pos >= 2u) { // fewer than three words left in the current block
+        philox(g.block, g.sample, g.pixel, 0u, k0, k1, n0, n1, n2, n3);
+        g.block++;
+    }
+    w0 = pos == 0u ? g.b0 : (pos == 1u ? g.b1 : (pos == 2u ? g.b2 : (pos == 3u ? g.b3 : n0)));
+    w1 = pos == 0u ? g.b1 : (pos == 1u ? g.b2 : (pos == 2u ? g.b3 : (pos == 3u ? n0 : n1)));
+    w2 = pos == 0u ? g.b2 : (pos == 1u ? g.b3 : (pos == 2u ? n0 : (pos == 3u ? n1 : n2)));
+    if (pos >= 2u) { g.b0 = n0; g.b1 = n1; g.b2 = n2; g.b3 = n3; g.pos = pos - 1u; } // 2->1, 3->2, 4->3
+    else g.pos = pos + 3u;
+}
+__device__ __forceinline__ void rng_take2(Rng &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1) {
+    uint32_t n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
+    const uint32_t pos = g.pos;
+    if (pos >= 3u) {
+        philox(g.block, g.sample, g.pixel, 0u, k0, k1, n0, n1, n2, n3);
+        g.block++;
+    }
+    w0 = pos == 0u ? g.b0 : (pos == 1u ? g.b1 : (pos == 2u ? g.b2 : (pos == 3u ? g.b3 : n0)));
+    w1 = pos == 0u ? g.b1 : (pos == 1u ? g.b2 : (pos == 2u ? g.b3 : (pos == 3u ? n0 : n1)));
+    if (pos >= 3u) { g.b0 = n0; g.b1 = n1; g.b2 = n2; g.b3 = n3; g.pos = pos - 2u; } // 3->1, 4->2
+    else g.pos = pos + 2u;
+}
+
+// src/util.rs:4-13 (draws x, y, z per trial)
+__device__ __forceinline__ F3 random_in_unit_sphere(Rng &g, uint32_t k0, uint32_t k1) {
+    for (;;) {
+        uint32_t w0, w1, w2;
+        rng_take3(g, k0, k1, w0, w1, w2);
+        const float x = rtmi_u01(w0), y = rtmi_u01(w1), z = rtmi_u01(w2);
+        F3 p = f3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
+        if (dot(p, p) < 1.0f) return p;
+    }
+}
+// src/util.rs:15-24 (draws x, y per trial)
+__device__ __forceinline__ F3 random_in_unit_disk(Rng &g, uint32_t k0, uint32_t k1) {
+    for (;;) {
+        uint32_t w0, w1;
+        rng_take2(g, k0, k1, w0, w1);
+        const float x = rtmi_u01(w0), y = rtmi_u01(w1);
+        F3 p = f3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 0.0f);
+        if (dot(p, p) < 1.0f) return p;
+    }
+}

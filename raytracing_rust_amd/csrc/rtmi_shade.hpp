@@ -1,0 +1,310 @@
+// rtmi_shade.hpp — textures, Perlin noise, materials, camera sample, medium sample, shading of one hit.
+// Part of the single translation unit rtmi_device.hip (device code is header-only so that every
+// kernel instantiation inlines the whole path); arithmetic contract as stated there.
+#pragma once
+#include "rtmi_rng.hpp"
+#include "rtmi_geom.hpp"
+
+// ----------------------------------------------------------------------------------
+// textures — src/texture.rs, src/perlin.rs
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t as_usize_u32(float x) { // Rust `as usize`, see DESIGN.md
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0u; // fp32 values >= 2^32 are multiples of 512: low 8 bits are 0
+    return (uint32_t)x;
+}
+// Perlin::noise + perlin_interpolation — perlin.rs:76-97, 38-56
+__device__ __forceinline__ float perlin_noise(const rtmi_perlin *pn, F3 p) {
+    const float fx = __builtin_floorf(p.x), fy = __builtin_floorf(p.y), fz = __builtin_floorf(p.z);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const uint32_t i = as_usize_u32(fx), j = as_usize_u32(fy), k = as_usize_u32(fz);
+    const float uu = u * u * (3.0f - 2.0f * u);
+    const float vv = v * v * (3.0f - 2.0f * v);
+    const float ww = w * w * (3.0f - 2.0f * w);
+    const float4 *rv = reinterpret_cast<const float4 *>(pn->ranvec);
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; di++)
+#pragma unroll
+        for (int dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (int dk = 0; dk < 2; dk++) {
+                const int h = pn->perm[(i + di) & 255u] ^ pn->perm[256 + ((j + dj) & 255u)] ^
+                              pn->perm[512 + ((k + dk) & 255u)];
+                const float4 c = rv[h];
+                const float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
+                const float fi = di ? uu : (1.0f - uu); // i*uu + (1-i)*(1-uu) with i in {0,1}
+                const float fj = dj ? vv : (1.0f - vv);
+                const float fk = dk ? ww : (1.0f - ww);
+                accum += fi * fj * fk * (c.x * wx + c.y * wy + c.z * wz);
+            }
+    return accum;
+}
+// Perlin::turb — perlin.rs:99-109
+__device__ __forceinline__ float perlin_turb(const rtmi_perlin *pn, F3 p, int depth) {
+    float accum = 0.0f, weight = 1.0f;
+    F3 tp = p;
+    for (int i = 0; i < depth; i++) {
+        accum += weight * perlin_noise(pn, tp);
+        weight *= 0.5f;
+        tp = tp * 2.0f;
+    }
+    return __builtin_fabsf(accum);
+}
+// Texture::value — texture.rs:21-25 (Solid), :39-48 (Checker), :65-71 (Noise), :86-108 (Image)
+__device__ __forceinline__ F3 tex_value(const DevScene &sc, int tex, float u, float v, F3 p) {
+    rtmi_texture t = sc.texs[tex];
+    for (int guard = 0; guard < 16 && t.kind == RTMI_TEX_CHECKER; guard++) {
+        const float s = rtmi_sinf(10.0f * p.x) * rtmi_sinf(10.0f * p.y) * rtmi_sinf(10.0f * p.z);
+        t = sc.texs[s < 0.0f ? t.i0 : t.i1];
+    }
+    if (t.kind == RTMI_TEX_NOISE) {
+        const float g = 0.5f * (1.0f + rtmi_sinf(t.f0 * p.x + 5.0f * perlin_turb(sc.perlin + t.i0, p, 7)));
+        return f3(g, g, g);
+    }
+    if (t.kind == RTMI_TEX_IMAGE) {
+        const rtmi_image im = sc.images[t.i0];
+        uint32_t i = as_usize_u32(u * (float)im.nx);
+        uint32_t j = as_usize_u32((1.0f - v) * (float)im.ny);
+        if (i > im.nx - 1) i = im.nx - 1;
+        if (j > im.ny - 1) j = im.ny - 1;
+        const uint8_t *px = sc.image_data + im.offset + 3ull * i + 3ull * im.nx * j;
+        return f3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    }
+    return f3(t.f0, t.f1, t.f2);
+}
+
+// get_sphere_uv — sphere.rs:9-15 (FRAC_2_PI, sic)
+__device__ __forceinline__ void sphere_uv(F3 n, float &u, float &v) {
+    const float phi = rtmi_atan2f(n.z, n.x);
+    const float theta = rtmi_asinf(n.y);
+    u = 1.0f - (phi + RTMI_PI_F) / (2.0f * RTMI_PI_F);
+    v = (theta + RTMI_2_OVER_PI_F) / RTMI_PI_F;
+}
+
+// ----------------------------------------------------------------------------------
+// materials — src/material.rs
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ F3 reflect(F3 v, F3 n) { // material.rs:9-11
+    const float s = 2.0f * dot(v, n);
+    return v - n * s;
+}
+__device__ __forceinline__ bool refract(F3 v, F3 n, float ni_over_nt, F3 &out) { // material.rs:13-23
+    const F3 uv = normalize(v);
+    const float dt = dot(uv, n);
+    const float disc = 1.0f - ni_over_nt * ni_over_nt * (1.0f - dt * dt);
+    if (disc > 0.0f) {
+        out = (uv - n * dt) * ni_over_nt - n * __builtin_sqrtf(disc);
+        return true;
+    }
+    return false;
+}
+__device__ __forceinline__ float schlick(float cosine, float ref_idx) { // material.rs:25-28
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    const float x = 1.0f - cosine;
+    const float x2 = x * x;
+    const float x4 = x2 * x2;
+    return r0 + (1.0f - r0) * (x * x4);
+}
+
+// ----------------------------------------------------------------------------------
+// path pieces shared by the render kernels
+// ----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sig_mix(uint32_t x, uint32_t k) {
+    x ^= (k + 1u) * 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+struct Path { // one camera path in flight (per lane)
+    F3 ro, rd;
+    float rtime;
+    F3 T, L;
+    uint32_t depth;
+};
+
+// next sample of this pixel: tests/test.rs:66-68 + Camera::get_ray (camera.rs:53-67)
+__device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevParams &P, Rng &g, uint32_t k0, uint32_t k1,
+                                              uint32_t s, uint32_t pixel, uint32_t px, uint32_t j, Path &pa) {
+    rng_init(g, s, pixel);
+    uint32_t wu, wv;
+    rng_take2(g, k0, k1, wu, wv); // u then v — tests/test.rs:66-67
+    const float u = ((float)px + rtmi_u01(wu)) / (float)P.nx;
+    const float v = ((float)j + rtmi_u01(wv)) / (float)P.ny;
+    F3 origin = cam.origin;
+    if (cam.lens_radius != 0.0f) {
+        const F3 rdk = random_in_unit_disk(g, k0, k1) * cam.lens_radius;
+        const F3 offset = cam.u * rdk.x + cam.v * rdk.y;
+        origin = cam.origin + offset;
+    }
+    pa.rtime = cam.time0 + rng_uniform(g, k0, k1) * (cam.time1 - cam.time0);
+    pa.ro = origin;
+    pa.rd = cam.llc + cam.horizontal * u + cam.vertical * v - origin;
+    pa.T = f3(1, 1, 1);
+    pa.L = f3(0, 0, 0);
+    pa.depth = 0;
+}
+
+// ConstantMedium::hit after both boundary queries — medium.rs:33-53.  Returns true when the
+// medium scatters before the boundary exit / the closest hit so far; the draw happens only when
+// the clamped interval is non-empty, as in the reference.
+__device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, F3 world_d,
+                                              float neg_inv_density, Rng &g, uint32_t k0, uint32_t k1, float &t_out) {
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > closest) t2 = closest;
+    if (t1 < t2) {
+        const float dn = norm(world_d);
+        const float dist_inside = (t2 - t1) * dn;
+        const float hit_distance = neg_inv_density * rtmi_logf(rng_uniform(g, k0, k1));
+        if (hit_distance < dist_inside) {
+            t_out = t1 + hit_distance / dn;
+            return true;
+        }
+    }
+    return false;
+}
+
+// HitRecord of the closest hit (hittable.rs:9-16), built once, then
+// color(): emitted + attenuation * color(scattered) — color.rs:8-15, in throughput form.
+// Returns true when the path continues (pa holds the scattered ray), false when it ended.
+__device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth, Rng &g, uint32_t k0, uint32_t k1,
+                                          float closest, int best_item, int best_pf, bool best_medium, Path &pa) {
+    const rtmi_item I = sc.items[best_item];
+    F3 hp, hn;
+    float hu = 0.0f, hv = 0.0f;
+    int mat_idx;
+    if (best_medium) {
+        hp = pa.ro + pa.rd * closest;      // ray.pointing_at(t) — medium.rs:47
+        hn = f3(1.0f, 0.0f, 0.0f);         // medium.rs:48
+        mat_idx = I.medium_material;
+    } else {
+        F3 lo = pa.ro, ld = pa.rd;
+        if (I.xform_count > 0) xform_ray(sc.xforms, I.xform_first, I.xform_count, lo, ld);
+        const int idx = best_pf >> 3, face = best_pf & 7;
+        const rtmi_prim_meta M = sc.meta[idx];
+        const float4 A = sc.prim_a[idx];
+        mat_idx = M.material;
+        const bool needs_uv = (sc.mats[mat_idx].flags & RTMI_MATFLAG_NEEDS_UV) != 0u;
+        hp = lo + ld * closest; // ray.pointing_at(t)
+        if (M.type == RTMI_PRIM_SPHERE || M.type == RTMI_PRIM_MSPHERE) {
+            F3 c = f3(A.x, A.y, A.z);
+            if (M.type == RTMI_PRIM_MSPHERE) c = moving_center(A, sc.prim_b[idx], M.inv_dt, pa.rtime);
+            hn = vdiv(hp - c, A.w); // sphere.rs:50 — outward, never face-forwarded
+            if (needs_uv) sphere_uv(hn, hu, hv);
+        } else {
+            int plane;
+            float x0, y0, x1, y1;
+            if (M.type == RTMI_PRIM_RECT) {
+                plane = (int)((M.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
+                x0 = A.x; y0 = A.y; x1 = A.z; y1 = A.w;
+            } else { // cube face -> its rect (cube.rs:21-74)
+                const float4 B = sc.prim_b[idx];
+                const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
+                if (face < 2) { plane = 2; x0 = ax; y0 = ay; x1 = bx; y1 = by; }
+                else if (face < 4) { plane = 1; x0 = az; y0 = ax; x1 = bz; y1 = bx; }
+                else { plane = 0; x0 = ay; y0 = az; x1 = by; y1 = bz; }
+            }
+            hn = f3(plane == 0 ? 1.0f : 0.0f, plane == 1 ? 1.0f : 0.0f, plane == 2 ? 1.0f : 0.0f); // rect.rs:58-59
+            if (needs_uv) { // rect.rs:52-56
+                const float x = plane == 0 ? lo.y + closest * ld.y : (plane == 1 ? lo.z + closest * ld.z : lo.x + closest * ld.x);
+                const float y = plane == 0 ? lo.z + closest * ld.z : (plane == 1 ? lo.x + closest * ld.x : lo.y + closest * ld.y);
+                hu = (x - x0) / (x1 - x0);
+                hv = (y - y0) / (y1 - y0);
+            }
+        }
+        if (I.xform_count > 0) xform_hit(sc.xforms, I.xform_first, I.xform_count, hp, hn);
+        if (((M.flags ^ I.flags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
+    }
+
+    // Material::emitted / Material::scatter (material.rs).  The rejection sampler and the texture
+    // lookup are needed by several materials; they are evaluated ONCE here for all lanes that need
+    // them (a per-material copy would run the same long code serially for each lane subset).  The
+    // draw order per lane is unchanged: Lambertian/Isotropic/fuzzy Metal draw only inside the sampler,
+    // Dielectric draws its single uniform, DiffuseLight draws nothing.
+    const rtmi_material M = sc.mats[mat_idx];
+    const int kind = M.kind;
+    const bool can_scatter = pa.depth < max_depth; // color.rs:9
+    const bool textured = kind == RTMI_MAT_LAMBERTIAN || kind == RTMI_MAT_METAL || kind == RTMI_MAT_ISOTROPIC;
+    const bool want_sample = can_scatter && (kind == RTMI_MAT_LAMBERTIAN || kind == RTMI_MAT_ISOTROPIC ||
+                                             (kind == RTMI_MAT_METAL && M.param > 0.0f));
+    F3 rs = f3(0, 0, 0);
+    if (want_sample) rs = random_in_unit_sphere(g, k0, k1);
+    F3 tv = f3(1, 1, 1);
+    if (kind == RTMI_MAT_DIFFUSE_LIGHT || (can_scatter && textured)) tv = tex_value(sc, M.tex, hu, hv, hp);
+    if (kind == RTMI_MAT_DIFFUSE_LIGHT) pa.L = pa.L + pa.T * tv; // material.rs:148-150
+    bool scattered = false;
+    const F3 rd = pa.rd;
+    F3 nd = rd, att = f3(1, 1, 1);
+    if (can_scatter) {
+        if (kind == RTMI_MAT_LAMBERTIAN) { // material.rs:49-53 (contract: dir = normal + rand)
+            nd = hn + rs;
+            att = tv;
+            scattered = true;
+        } else if (kind == RTMI_MAT_METAL) { // material.rs:75-87
+            F3 refl = reflect(normalize(rd), hn);
+            if (M.param > 0.0f) refl = refl + rs * M.param;
+            if (dot(refl, hn) > 0.0f) {
+                nd = refl;
+                att = tv;
+                scattered = true;
+            }
+        } else if (kind == RTMI_MAT_DIELECTRIC) { // material.rs:106-126
+            F3 outward;
+            float ni_over_nt, cosine;
+            const float ddn = dot(rd, hn);
+            if (ddn > 0.0f) {
+                cosine = M.param * ddn / norm(rd);
+                outward = -hn;
+                ni_over_nt = M.param;
+            } else {
+                cosine = -ddn / norm(rd);
+                outward = hn;
+                ni_over_nt = 1.0f / M.param;
+            }
+            F3 refr;
+            bool took_refraction = false;
+            if (refract(rd, outward, ni_over_nt, refr)) {
+                const float reflect_prob = schlick(cosine, M.param);
+                if (rng_uniform(g, k0, k1) >= reflect_prob) { nd = refr; took_refraction = true; }
+            }
+            if (!took_refraction) nd = reflect(rd, hn);
+            scattered = true;
+        } else if (kind == RTMI_MAT_ISOTROPIC) { // material.rs:165-168
+            nd = rs;
+            att = tv;
+            scattered = true;
+        }
+    }
+    if (scattered) {
+        pa.T = pa.T * att;
+        pa.ro = hp;
+        pa.rd = nd;
+        pa.depth++;
+    }
+    return scattered;
+}
+
+// work item of a wavefront: (sample chunk, local tile) -> pixel of this lane
+struct LaneJob {
+    uint32_t item, ltile, px, j, pixel, s_begin, s_end;
+    bool in_image, wave_has_work;
+};
+__device__ __forceinline__ LaneJob lane_job(const DevParams &P, int wave, int lane) {
+    LaneJob J;
+    J.item = blockIdx.x * WAVES_PER_BLOCK + wave; // (chunk, local tile)
+    const uint32_t nitems = P.ntiles_local * P.nchunks;
+    J.wave_has_work = J.item < nitems;
+    const uint32_t chunk = J.item / P.ntiles_local;
+    J.ltile = J.item - chunk * P.ntiles_local;
+    const uint32_t tile = J.ltile * P.tile_world + P.tile_rank;
+    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    J.px = tx * RTMI_TILE + (lane & 7);
+    const uint32_t row = ty * RTMI_TILE + (lane >> 3);
+    J.in_image = J.px < P.nx && row < P.ny;
+    J.j = P.ny - 1u - row;          // `for j in (0..ny).rev()` — tests/test.rs:62
+    J.pixel = J.j * P.nx + J.px;    // stream id of this pixel
+    J.s_begin = (uint32_t)(((uint64_t)P.ns * chunk) / P.nchunks);
+    J.s_end = (uint32_t)(((uint64_t)P.ns * (chunk + 1)) / P.nchunks);
+    return J;
+}

@@ -1,0 +1,67 @@
+// rtmi_types.hpp — vector type and the device-side views of scene, camera and render parameters.
+// Part of the single translation unit rtmi_device.hip (device code is header-only so that every
+// kernel instantiation inlines the whole path); arithmetic contract as stated there.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rtmi.h"
+#include "rtmi_math.h"
+
+#define RTMI_FLT_MAX 3.40282346638528859811704183484516925e+38f
+#define WAVES_PER_BLOCK 1
+
+// ----------------------------------------------------------------------------------
+// small vector type with explicit operation order (nalgebra Vector3 semantics)
+// ----------------------------------------------------------------------------------
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ F3 vdiv(F3 a, float s) { return f3(a.x / s, a.y / s, a.z / s); }
+__device__ __forceinline__ float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float norm(F3 a) { return __builtin_sqrtf(dot(a, a)); }
+__device__ __forceinline__ F3 normalize(F3 a) { return vdiv(a, norm(a)); }
+template <int I>
+__device__ __forceinline__ float comp(F3 a) {
+    return I == 0 ? a.x : (I == 1 ? a.y : a.z);
+}
+
+struct DevScene {
+    const rtmi_item *items;
+    const float4 *prim_a;
+    const float4 *prim_b;
+    const rtmi_prim_meta *meta;
+    const float4 *nodes; // 4 x float4 per rtmi_bvh_node
+    const rtmi_xform *xforms;
+    const rtmi_material *mats;
+    const rtmi_texture *texs;
+    const rtmi_perlin *perlin;
+    const rtmi_image *images;
+    const uint8_t *image_data;
+    uint32_t n_items;
+};
+
+struct DevCamera {
+    F3 origin, llc, horizontal, vertical, u, v;
+    float time0, time1, lens_radius;
+};
+
+struct DevParams {
+    uint32_t nx, ny, ns, max_depth;
+    float t_min;
+    uint32_t key0, key1;
+    uint32_t tile_rank, tile_world, tiles_x, ntiles_local, nchunks;
+    unsigned long long *path_sig;
+    unsigned long long *prof;
+    uint32_t stack_depth;
+    uint32_t shade_threshold;
+    uint32_t coop_cap;
+    unsigned int *status;
+};
