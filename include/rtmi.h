@@ -167,6 +167,8 @@ typedef struct {
 #define RTMI_FLAG_PROFILE 4u   /* diagnostics build: lane-activity counters into prof (64 uint64); slow */
 #define RTMI_FLAG_SYNC 8u      /* per-lane BVH traversal instead of the wave-cooperative one (exact mode always is) */
 #define RTMI_FLAG_ASYNC 16u    /* per-lane state-machine kernel (experimental, kept for comparison) */
+#define RTMI_FLAG_SKY 32u      /* opt-in extension, off by default: a ray that misses the world returns the gradient
+                                * the reference keeps commented out at src/color.rs:18-20 instead of black (:21) */
 typedef struct {
     uint32_t nx, ny, ns; /* create_image(ny, nx, ns, ..) */
     uint32_t max_depth;  /* 50 (color.rs:9) */

@@ -18,6 +18,7 @@ _BUILD = os.path.join(_HERE, "_build")
 
 ARITH_DEVICE = 1
 THROUGHPUT_FORM = 2
+SKY = 4  # opt-in extension: gradient background of color.rs:18-20 (commented out in the reference)
 
 COUNTER_NAMES = [
     "samples", "queries", "aabb", "sphere", "msphere", "rect", "xform", "medium", "medium_draw",

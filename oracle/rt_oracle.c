@@ -63,7 +63,9 @@ typedef double REAL;
 /* ---- run-time switches -------------------------------------------------------- */
 enum {
     ORC_ARITH_DEVICE = 1,  /* fp32 arithmetic contract substitutions      */
-    ORC_THROUGHPUT_FORM = 2 /* iterative L += T*e form of color() instead of the recursion */
+    ORC_THROUGHPUT_FORM = 2, /* iterative L += T*e form of color() instead of the recursion */
+    ORC_SKY = 4              /* opt-in extension: the gradient background the reference keeps
+                              * commented out at color.rs:18-20 (default: black, color.rs:21)  */
 };
 static int g_flags = 0;
 #define DEVICE_ARITH (g_flags & ORC_ARITH_DEVICE)
@@ -778,6 +780,14 @@ static uint32_t sig_mix(uint32_t x, uint32_t k) {
 }
 static void sig_add(REAL t, int depth) { g_sig += (uint64_t)sig_mix(rtmi_f2u((float)t), (uint32_t)depth); }
 
+/* color.rs:18-20 (commented out in the reference; rendered only under ORC_SKY) */
+static V3 sky_color(V3 d) {
+    V3 unit = v_normalize(d);
+    REAL t = (REAL)0.5 * (unit.y + (REAL)1.0);
+    REAL a = (REAL)1.0 - t;
+    return v3(a * (REAL)1.0 + t * (REAL)0.5, a * (REAL)1.0 + t * (REAL)0.7, a * (REAL)1.0 + t * (REAL)1.0);
+}
+
 static V3 color(const RenderCtx *cx, const Ray *ray, int depth) {
     HitRecord rec;
     COUNT(C_QUERIES);
@@ -794,6 +804,7 @@ static V3 color(const RenderCtx *cx, const Ray *ray, int depth) {
         }
         return emitted;
     }
+    if (g_flags & ORC_SKY) return sky_color(ray->d);
     return v3(0, 0, 0); /* background is black (color.rs:21) */
 }
 
@@ -804,7 +815,10 @@ static V3 color_throughput(const RenderCtx *cx, Ray ray) {
     for (int depth = 0;; depth++) {
         HitRecord rec;
         COUNT(C_QUERIES);
-        if (!hit(cx->world, &ray, cx->t_min, R_MAX, &rec)) break;
+        if (!hit(cx->world, &ray, cx->t_min, R_MAX, &rec)) {
+            if (g_flags & ORC_SKY) L = v_add(L, v_mul(T, sky_color(ray.d)));
+            break;
+        }
         sig_add(rec.t, depth);
         V3 emitted = mat_emitted(rec.mat, rec.u, rec.v, rec.p);
         L = v_add(L, v_mul(T, emitted));

@@ -17,6 +17,7 @@ RTMI_FLAG_PATH_SIG = 2
 RTMI_FLAG_PROFILE = 4
 RTMI_FLAG_SYNC = 8
 RTMI_FLAG_ASYNC = 16
+RTMI_FLAG_SKY = 32
 
 TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
@@ -196,6 +197,7 @@ def load_host():
         "rth_scatter": (i, [vp, vp, vp, d, vp, u64, vp, vp]),
         "rth_emitted": (i, [vp, d, d, vp, vp]),
         "rth_get_ray": (i, [vp, d, d, u64, vp]),
+        "rth_set_sky_background": (None, [i]),
         "rth_color_sample": (i, [vp, vp, u32, u32, u32, u32, u32, u64, vp]),
     }
     for name, (res, args) in sig.items():

@@ -296,7 +296,9 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     const bool coop_ok = s->meta.n_prims < (1u << 22) && s->meta.n_nodes < (1u << 25);
     const bool coop = fast && !sync && !async && coop_ok;
     P.status = s->status;
+    P.sky = (p->flags & RTMI_FLAG_SKY) ? 1u : 0u;
     P.coop_cap = 64u * (s->meta.max_bvh_depth + 2u);
+    if (p->flags & (1u << 11)) P.coop_cap -= 64u; // experiment knob: LDS footprint just under 10 KB per wave
     const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u) * sizeof(uint32_t);
 #define RTMI_LAUNCH(KERN, F, S, PR, LDS) hipLaunchKernelGGL((KERN<F, S, PR>), grid, block, LDS, stream, s->dev, C, P, s->partial)
 #define RTMI_LAUNCH_COOP(S, PR, W)                                                                                       \
@@ -310,6 +312,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
         const uint32_t wps = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
         if (prof) RTMI_LAUNCH_COOP(false, true, 3);
         else if (sigf) RTMI_LAUNCH_COOP(true, false, 4);
+        else if (wps == 2) RTMI_LAUNCH_COOP(false, false, 2);
         else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3);
         else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5);
         else RTMI_LAUNCH_COOP(false, false, 4);

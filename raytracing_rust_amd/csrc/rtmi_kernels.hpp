@@ -94,6 +94,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                 if (best_item >= 0) {
                     have_hit = true;
                 } else { // miss: black background (color.rs:21); the path ends, next sample
+                    if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
                     acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
                     s++; alive = false;
                     done = s >= J.s_end;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (best_item >= 0) {
                     have_hit = true;
                 } else { // miss: black background (color.rs:21)
+                    if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
                     acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
                     s++; alive = false;
                     done = s >= J.s_end;
@@ -420,6 +422,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                     if (it >= n_items) {
                         if (best_item >= 0) { st = ST_SHADE; }
                         else { // miss: black background (color.rs:21)
+                            if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
                             acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
                             s++; st = ST_NEW;
                         }

@@ -111,6 +111,15 @@ __device__ __forceinline__ float schlick(float cosine, float ref_idx) { // mater
 // ----------------------------------------------------------------------------------
 // path pieces shared by the render kernels
 // ----------------------------------------------------------------------------------
+// opt-in extension (RTMI_FLAG_SKY): the background gradient the reference keeps commented out at
+// color.rs:18-20; a path that leaves the scene adds T * sky(direction) instead of black (:21)
+__device__ __forceinline__ F3 sky_color(F3 d) {
+    const F3 unit = normalize(d);
+    const float t = 0.5f * (unit.y + 1.0f);
+    const float a = 1.0f - t;
+    return f3(a * 1.0f + t * 0.5f, a * 1.0f + t * 0.7f, a * 1.0f + t * 1.0f);
+}
+
 __device__ __forceinline__ uint32_t sig_mix(uint32_t x, uint32_t k) {
     x ^= (k + 1u) * 0x9E3779B9u;
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;

@@ -64,4 +64,5 @@ struct DevParams {
     uint32_t shade_threshold;
     uint32_t coop_cap;
     unsigned int *status;
+    uint32_t sky; // RTMI_FLAG_SKY
 };

@@ -320,9 +320,14 @@ class Host:
         self._check(self.lib.rth_emitted(mat.h, u, v, pp.ctypes.data, out.ctypes.data))
         return out
 
-    def color_sample(self, cam, world, nx, ny, i, j, s, seed=42):
+    def color_sample(self, cam, world, nx, ny, i, j, s, seed=42, sky=False):
+        """color() of one camera sample on the CPU mirror; sky=True = the opt-in background of color.rs:18-20."""
         out = np.zeros(3)
-        self._check(self.lib.rth_color_sample(cam.h, world.h, nx, ny, i, j, s, seed, out.ctypes.data))
+        self.lib.rth_set_sky_background(1 if sky else 0)
+        try:
+            self._check(self.lib.rth_color_sample(cam.h, world.h, nx, ny, i, j, s, seed, out.ctypes.data))
+        finally:
+            self.lib.rth_set_sky_background(0)
         return out
 
     def perlin_tables(self, tex):

@@ -206,14 +206,16 @@ Camera set_camera(size_t nx, size_t ny, const Vec3 &look_from, const Vec3 &look_
 
 int main(int argc, char **argv) {
     if (argc < 6) {
-        fprintf(stderr, "usage: %s <scene> <nx> <ny> <ns> <out.ppm> [seed=42] [scene_seed=1] [earth.rgb8 nx ny]\n", argv[0]);
+        fprintf(stderr, "usage: %s <scene>[+sky] <nx> <ny> <ns> <out.ppm> [seed=42] [scene_seed=1] [earth.rgb8 nx ny]\n", argv[0]);
         return 2;
     }
-    const std::string name = argv[1];
+    std::string name = argv[1];
+    bool sky = false; // "<scene>+sky": opt-in background of color.rs:18-20 (RTMI_FLAG_SKY); default black (:21)
+    if (name.size() > 4 && name.compare(name.size() - 4, 4, "+sky") == 0) { sky = true; name.resize(name.size() - 4); }
     const size_t nx = (size_t)atol(argv[2]), ny = (size_t)atol(argv[3]), ns = (size_t)atol(argv[4]);
     RenderOptions opt;
     opt.seed = argc > 6 ? strtoull(argv[6], nullptr, 10) : 42;
-    opt.flags = RTMI_FLAG_FAST_CULL;
+    opt.flags = RTMI_FLAG_FAST_CULL | (sky ? RTMI_FLAG_SKY : 0u);
     const uint64_t scene_seed = argc > 7 ? strtoull(argv[7], nullptr, 10) : 1;
     if (argc > 10) {
         std::ifstream f(argv[8], std::ios::binary);

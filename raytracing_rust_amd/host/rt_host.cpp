@@ -433,6 +433,10 @@ std::optional<std::pair<Ray, Vec3>> Isotropic::scatter(const Ray &ray, const Hit
 }
 
 // ---- src/color.rs:6-23 -------------------------------------------------------------------
+static thread_local bool g_sky_background = false;
+void set_sky_background(bool on) { g_sky_background = on; }
+bool sky_background() { return g_sky_background; }
+
 Vec3 color(const Ray &ray, const Hittable &world, size_t depth) {
     if (auto hit = world.hit(ray, 0.001, kF64Max)) {
         const Vec3 emitted = hit->material->emitted(hit->u, hit->v, hit->p);
@@ -441,6 +445,11 @@ Vec3 color(const Ray &ray, const Hittable &world, size_t depth) {
                 return emitted + sc->second.zip_mul(color(sc->first, world, depth + 1));
         }
         return emitted;
+    }
+    if (g_sky_background) { // color.rs:18-20
+        const Vec3 unit_direction = ray.direction().normalize();
+        const double t = 0.5 * (unit_direction.y + 1.0);
+        return Vec3(1.0, 1.0, 1.0) * (1.0 - t) + Vec3(0.5, 0.7, 1.0) * t;
     }
     return Vec3(0.0, 0.0, 0.0);
 }

@@ -314,6 +314,11 @@ Vec3 random_in_unit_disk();
 
 // ---- src/color.rs -------------------------------------------------------------------------
 Vec3 color(const Ray &ray, const Hittable &world, size_t depth);
+// Opt-in extension, off by default: a missing ray returns the gradient the reference keeps commented out at
+// color.rs:18-20 instead of black (:21).  Thread-local switch for the CPU evaluation; the device takes
+// RTMI_FLAG_SKY in RenderOptions::flags.
+void set_sky_background(bool on);
+bool sky_background();
 
 // ---- lowering to the flat device scene ----------------------------------------------------
 struct LoweredScene {

@@ -330,6 +330,7 @@ RTH_API int rth_get_ray(void *cam, double s, double t, uint64_t seed, double *ou
         return RTH_OK;
     });
 }
+RTH_API void rth_set_sky_background(int on) { set_sky_background(on != 0); }
 // color() of one camera sample on the CPU (f64), same stream layout as the device
 RTH_API int rth_color_sample(void *cam, void *world, uint32_t nx, uint32_t ny, uint32_t i, uint32_t j, uint32_t s,
                              uint64_t seed, double *out3) {
