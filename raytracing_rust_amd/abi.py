@@ -88,7 +88,7 @@ class RenderParams(C.Structure):
     _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("ns", C.c_uint32), ("max_depth", C.c_uint32),
                 ("t_min", C.c_float), ("flags", C.c_uint32), ("seed", C.c_uint64),
                 ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("spp_chunks", C.c_uint32), ("shade_threshold", C.c_uint32),
-                ("path_sig", C.c_uint64), ("prof", C.c_uint64)]
+                ("path_sig", C.c_uint64), ("prof", C.c_uint64), ("sample_buffer_bytes", C.c_uint64)]
 
 
 class Texel(C.Structure):

@@ -46,9 +46,13 @@ struct rtmi_scene {
     DevScene dev{};
     std::vector<void *> allocs;
     rtmi_scene_desc meta{}; // counts only (pointers nulled)
-    double *partial = nullptr;
+    double *partial = nullptr; // f64 radiance sums [local tile][3][64], carried between passes
     size_t partial_bytes = 0;
-    unsigned int *status = nullptr; // device word: cooperative-traversal pool overflows (must stay 0)
+    float4 *samples = nullptr; // per-sample radiance [local tile][pass samples][64]
+    size_t samples_bytes = 0;
+    unsigned int *status = nullptr; // device words: [0] cooperative-traversal pool overflows (must stay 0),
+                                    // [1] unit counter of the persistent wavefronts
+    int slots = 0;                  // CUs x 16: resident wavefronts the render kernels are launched with
     rtmi_texel *texels = nullptr; // scratch for the blocking host API
     size_t texel_count = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -179,10 +183,15 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     }
     s->dev.nodes = nodes4;
     s->dev.n_items = d->n_items;
-    if (hipMalloc(reinterpret_cast<void **>(&s->status), sizeof(unsigned int)) != hipSuccess ||
-        hipMemset(s->status, 0, sizeof(unsigned int)) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&s->status), 2 * sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(s->status, 0, 2 * sizeof(unsigned int)) != hipSuccess) {
         rtmi_scene_destroy(s);
         return fail(RTMI_ERR_DEVICE, "allocating the status word failed");
+    }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+        s->slots = cus * 16; // 4 SIMDs x 4 wavefronts (the __launch_bounds__ of the default kernel)
     }
     for (int i = 0; i < 3; i++)
         if (hipEventCreate(&s->ev[i]) != hipSuccess) {
@@ -198,6 +207,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->partial) (void)hipFree(s->partial);
+    if (s->samples) (void)hipFree(s->samples);
     if (s->texels) (void)hipFree(s->texels);
     if (s->status) (void)hipFree(s->status);
     for (int i = 0; i < 3; i++)
@@ -221,6 +231,7 @@ static int check_params(const rtmi_render_params *p) {
     if (!p) return fail(RTMI_ERR_INVALID, "params is NULL");
     if (p->nx == 0 || p->ny == 0 || p->ns == 0) return fail(RTMI_ERR_INVALID, "nx, ny and ns must be positive");
     if ((uint64_t)p->nx * p->ny > 0xffffffffull) return fail(RTMI_ERR_UNSUPPORTED, "image too large");
+    if (p->ns >= (1u << 26)) return fail(RTMI_ERR_UNSUPPORTED, "ns must be below 2^26");
     if (p->tile_world == 0 || p->tile_rank >= p->tile_world) return fail(RTMI_ERR_INVALID, "bad tile_rank/tile_world");
     return RTMI_OK;
 }
@@ -242,24 +253,57 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
         if (stats) memset(stats, 0, sizeof(*stats));
         return RTMI_OK;
     }
-    // split the sample range so that the grid holds many more wavefronts than the chip
-    // has slots (256 CUs x 16): balances tiles of very different path lengths
-    uint32_t chunks = p->spp_chunks;
-    if (chunks == 0) {
-        const uint32_t target_items = 256u * 16u * 8u;
-        chunks = (target_items + P.ntiles_local - 1) / P.ntiles_local;
-        if (chunks > 64u) chunks = 64u;
-    }
-    if (chunks > p->ns) chunks = p->ns;
-    if (chunks == 0) chunks = 1;
-    P.nchunks = chunks;
     P.path_sig = reinterpret_cast<unsigned long long *>(p->path_sig);
     if (p->flags & RTMI_FLAG_PATH_SIG) {
         if (!p->path_sig) return fail(RTMI_ERR_INVALID, "RTMI_FLAG_PATH_SIG needs params.path_sig");
         HIP_TRY(hipMemsetAsync(P.path_sig, 0, (size_t)P.ntiles_local * 64 * sizeof(unsigned long long), stream));
     }
 
-    const size_t need = (size_t)P.ntiles_local * chunks * 64 * 3 * sizeof(double);
+    // ---- per-sample buffer and passes.  Every finished path stores its radiance (16 B) in
+    // samples[local tile][sample of the pass][pixel]; the resolve kernel adds them in sample order.  With
+    // 288 GB of HBM the whole sample range normally fits (headline: 33 GB); otherwise the range is rendered
+    // in passes and the f64 sums are carried between them — the same additions in the same order.
+    const size_t per_sample = (size_t)P.ntiles_local * 64 * sizeof(float4);
+    const size_t want = p->sample_buffer_bytes ? (size_t)p->sample_buffer_bytes : ((size_t)48 << 30);
+    uint64_t max_pass = want / per_sample;
+    if (max_pass < 1) max_pass = 1;
+    if (max_pass > p->ns) max_pass = p->ns;
+    if (max_pass * per_sample > s->samples_bytes) {
+        if (!p->sample_buffer_bytes) { // default budget: never more than 3/4 of what is free on the device
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const size_t avail = (free_b + s->samples_bytes) / 4 * 3;
+            if (max_pass * per_sample > avail) max_pass = avail / per_sample ? avail / per_sample : 1;
+        }
+        if (max_pass * per_sample > s->samples_bytes) {
+            if (s->samples) { HIP_TRY(hipFree(s->samples)); s->samples = nullptr; s->samples_bytes = 0; }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->samples), max_pass * per_sample));
+            s->samples_bytes = max_pass * per_sample;
+        }
+    }
+    // unit = (tile, chunk of the sample range), the grain of the persistent wavefronts' queue.  Lanes
+    // take (sample, pixel) items dynamically and a wavefront moves on to the next unit without
+    // draining, so units can be small: the launch ends within about one heavy unit of the last
+    // wavefront.  Small images still get a few units per wavefront slot.
+    uint32_t chunk_spp;
+    if (p->spp_chunks) {
+        chunk_spp = (p->ns + p->spp_chunks - 1) / p->spp_chunks;
+    } else {
+        chunk_spp = 16u;
+        const uint64_t want_units = (uint64_t)s->slots * 4u;
+        if ((uint64_t)P.ntiles_local * ((p->ns + chunk_spp - 1) / chunk_spp) < want_units) {
+            const uint64_t per_tile = (want_units + P.ntiles_local - 1) / P.ntiles_local;
+            chunk_spp = (uint32_t)((p->ns + per_tile - 1) / per_tile);
+        }
+    }
+    if (chunk_spp > max_pass) chunk_spp = (uint32_t)max_pass;
+    if (chunk_spp < 1u) chunk_spp = 1u;
+    const uint32_t pass_ns = (uint32_t)(max_pass / chunk_spp) * chunk_spp; // whole chunks per pass
+    P.chunk_spp = chunk_spp;
+    P.pass_stride = pass_ns;
+    P.samples = s->samples;
+
+    const size_t need = (size_t)P.ntiles_local * 64 * 3 * sizeof(double); // f64 sums carried between passes
     if (need > s->partial_bytes) {
         if (s->partial) { HIP_TRY(hipFree(s->partial)); s->partial = nullptr; s->partial_bytes = 0; }
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->partial), need));
@@ -275,11 +319,9 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     C.v = F3{cam->v[0], cam->v[1], cam->v[2]};
     C.time0 = cam->time0; C.time1 = cam->time1; C.lens_radius = cam->lens_radius;
 
-    const uint32_t nitems = P.ntiles_local * chunks;
-    const uint32_t blocks = (nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (stats) HIP_TRY(hipEventRecord(s->ev[0], stream));
     const bool fast = (p->flags & RTMI_FLAG_FAST_CULL) != 0u, sigf = (p->flags & RTMI_FLAG_PATH_SIG) != 0u;
-    const dim3 grid(blocks), block(64 * WAVES_PER_BLOCK);
+    const dim3 block(64 * WAVES_PER_BLOCK);
     P.stack_depth = s->meta.max_bvh_depth + 1u;
     P.shade_threshold = p->shade_threshold ? (p->shade_threshold > 64u ? 64u : p->shade_threshold) : 1u;
     const size_t dyn_lds = (size_t)WAVES_PER_BLOCK * 2u * P.stack_depth * 64u * sizeof(uint32_t);
@@ -296,23 +338,36 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     const bool coop_ok = s->meta.n_prims < (1u << 22) && s->meta.n_nodes < (1u << 25);
     const bool coop = fast && !sync && !async && coop_ok;
     P.status = s->status;
+    P.queue = s->status + 1;
     P.sky = (p->flags & RTMI_FLAG_SKY) ? 1u : 0u;
     P.coop_cap = 64u * (s->meta.max_bvh_depth + 2u);
-    if (p->flags & (1u << 11)) P.coop_cap -= 64u; // experiment knob: LDS footprint just under 10 KB per wave
     const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u) * sizeof(uint32_t);
-#define RTMI_LAUNCH(KERN, F, S, PR, LDS) hipLaunchKernelGGL((KERN<F, S, PR>), grid, block, LDS, stream, s->dev, C, P, s->partial)
+    const uint32_t ntex = P.ntiles_local * 64u;
+    uint32_t blocks_total = 0, chunks_total = 0;
+    for (uint32_t s0 = 0; s0 < p->ns; s0 += pass_ns) { // one pass unless the sample buffer is smaller than ns samples
+    P.pass_s0 = s0;
+    P.pass_cnt = p->ns - s0 < pass_ns ? p->ns - s0 : pass_ns;
+    P.nchunks = (P.pass_cnt + chunk_spp - 1) / chunk_spp;
+    const uint64_t nitems = (uint64_t)P.ntiles_local * P.nchunks;
+    if (nitems > 0x7fffffffull) return fail(RTMI_ERR_UNSUPPORTED, "too many (tile, chunk) items in one pass");
+    // two-phase kernels: persistent wavefronts that take units from the queue; async kernel: one block per unit
+    const uint64_t nblocks = async ? (nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK
+                                   : (nitems < (uint64_t)s->slots ? nitems : (uint64_t)s->slots);
+    const dim3 grid((uint32_t)nblocks);
+    blocks_total += grid.x; chunks_total += P.nchunks;
+    HIP_TRY(hipMemsetAsync(s->status + 1, 0, sizeof(unsigned int), stream));
+#define RTMI_LAUNCH(KERN, F, S, PR, LDS) hipLaunchKernelGGL((KERN<F, S, PR>), grid, block, LDS, stream, s->dev, C, P)
 #define RTMI_LAUNCH_COOP(S, PR, W)                                                                                       \
     do {                                                                                                                 \
         if (coop_lds > 48u * 1024u)                                                                                      \
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi_render_coop<S, PR, W>),                     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds));                     \
-        hipLaunchKernelGGL((rtmi_render_coop<S, PR, W>), grid, block, coop_lds, stream, s->dev, C, P, s->partial);       \
+        hipLaunchKernelGGL((rtmi_render_coop<S, PR, W>), grid, block, coop_lds, stream, s->dev, C, P);                   \
     } while (0)
     if (coop) {
         const uint32_t wps = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
         if (prof) RTMI_LAUNCH_COOP(false, true, 3);
         else if (sigf) RTMI_LAUNCH_COOP(true, false, 4);
-        else if (wps == 2) RTMI_LAUNCH_COOP(false, false, 2);
         else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3);
         else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5);
         else RTMI_LAUNCH_COOP(false, false, 4);
@@ -332,11 +387,12 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
 #undef RTMI_LAUNCH
 #undef RTMI_LAUNCH_COOP
     HIP_TRY(hipGetLastError());
-    if (stats) HIP_TRY(hipEventRecord(s->ev[1], stream));
-    const uint32_t ntex = P.ntiles_local * 64u;
-    hipLaunchKernelGGL(rtmi_resolve_kernel, dim3((ntex + 255) / 256), dim3(256), 0, stream, s->partial,
-                       reinterpret_cast<rtmi_texel *>(d_texels), P);
+    const bool last = s0 + P.pass_cnt >= p->ns;
+    if (stats && last) HIP_TRY(hipEventRecord(s->ev[1], stream));
+    hipLaunchKernelGGL(rtmi_resolve_kernel, dim3((ntex + 255) / 256), dim3(256), 0, stream, s->samples, s->partial,
+                       reinterpret_cast<rtmi_texel *>(d_texels), P, s0 == 0 ? 1 : 0, last ? 1 : 0);
     HIP_TRY(hipGetLastError());
+    } // passes
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev[2], stream));
         HIP_TRY(hipEventSynchronize(s->ev[2]));
@@ -356,7 +412,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
             pix += (uint64_t)w * h;
         }
         stats->samples = pix * p->ns;
-        stats->tiles = P.ntiles_local; stats->chunks = chunks; stats->blocks = blocks; stats->reserved = 0;
+        stats->tiles = P.ntiles_local; stats->chunks = chunks_total; stats->blocks = blocks_total; stats->reserved = 0;
         unsigned int st = 0;
         HIP_TRY(hipMemcpy(&st, s->status, sizeof(st), hipMemcpyDeviceToHost));
         if (st != 0) return fail(RTMI_ERR_DEVICE, "cooperative traversal pool overflow (results invalid): use RTMI_FLAG_SYNC");

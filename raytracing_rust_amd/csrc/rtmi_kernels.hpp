@@ -18,8 +18,7 @@
 // results do not depend on the threshold.
 // ----------------------------------------------------------------------------------
 template <bool FAST, bool SIG, bool PROF>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevScene sc, DevCamera cam, DevParams P,
-                                                                           double *__restrict__ partial) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevScene sc, DevCamera cam, DevParams P) {
     __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
     unsigned long long *prof = prof_lds;
     if (PROF) {
@@ -32,14 +31,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
     const int wave = threadIdx.x >> 6;
     uint32_t *stack = &lds_stack[wave][0][0][lane];
     unsigned long long sig = 0ull;
-    const LaneJob J = lane_job(P, wave, lane);
-    if (!PROF && !J.wave_has_work) return;
+    WaveWork w;
+    w.ltile = 0u; w.s_begin = 0u; w.x0 = 0u; w.y0 = 0u; w.cols = 0u; w.n_valid = 0u; w.next = 0u; w.total = 0u;
+    bool queue_empty = false;
     const uint32_t k0 = P.key0, k1 = P.key1;
     const int threshold = (int)P.shade_threshold;
 
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0; // `col += color(..)` — tests/test.rs:69 (f64 like the reference)
-    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
-    bool alive = false, done = s >= J.s_end, have_hit = false;
+    uint32_t ps = 0u, ltile = 0u; // the item (sample, pixel) and the local tile this lane's path belongs to
+    bool alive = false, done = false, have_hit = false;
     Rng g;
     rng_init(g, 0, 0);
     Path pa;
@@ -51,14 +50,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
     for (;;) {
         // ================= phase A: trace until enough lanes hold a hit =================
         for (;;) {
+            if (__ballot(!have_hit && !done) == 0ull) break;
+            { // lanes whose path ended take the next (sample, pixel) item of the chunk
+                const bool want = !have_hit && !done && !alive;
+                if (__ballot(want) != 0ull) {
+                    if (work_take(w, queue_empty, want, cam, P, g, k0, k1, ps, ltile, pa)) alive = true;
+                    else if (want) done = true;
+                }
+            }
             const bool need = !have_hit && !done;
-            if (__ballot(need) == 0ull) break;
             prof_tick<PROF>(prof, 0, need);
             if (need) {
-                if (!alive) {
-                    camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
-                    alive = true;
-                }
                 // ---- world.hit(ray, 0.001, f64::MAX): scan of the top-level list (hittable.rs:37-47)
                 RayF W;
                 W.o = pa.ro; W.d = pa.rd;
@@ -93,11 +95,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                 }
                 if (best_item >= 0) {
                     have_hit = true;
-                } else { // miss: black background (color.rs:21); the path ends, next sample
+                } else { // miss: black background (color.rs:21); the path ends
                     if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
-                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
-                    s++; alive = false;
-                    done = s >= J.s_end;
+                    path_end(P, ltile, ps, pa);
+                    if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (ps & 63u), sig); sig = 0ull; }
+                    alive = false;
                 }
             }
             if (__popcll(__ballot(have_hit)) >= threshold) break;
@@ -110,9 +112,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
             if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
             if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
                 // absorbed, emitter or depth limit: the path ends
-                acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
-                s++; alive = false;
-                done = s >= J.s_end;
+                path_end(P, ltile, ps, pa);
+                if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (ps & 63u), sig); sig = 0ull; }
+                alive = false;
             }
         }
     }
@@ -120,12 +122,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
     if (PROF) {
         __syncthreads();
         if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
-        if (!J.wave_has_work) return;
     }
-    // partial[chunk][ltile][channel][lane]
-    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
-    out[0] = acc0; out[64] = acc1; out[128] = acc2;
-    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig); // integer add: order-independent
 }
 
 // ----------------------------------------------------------------------------------
@@ -134,8 +131,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
 // without a pending query are workers for the others' BVH traversals).
 // ----------------------------------------------------------------------------------
 template <bool SIG, bool PROF, int WPS>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(DevScene sc, DevCamera cam, DevParams P,
-                                                                              double *__restrict__ partial) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(DevScene sc, DevCamera cam, DevParams P) {
     __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
     unsigned long long *prof = prof_lds;
     if (PROF) {
@@ -148,14 +144,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     const int cap = (int)P.coop_cap;
     uint32_t *wlds = lds_dyn + (size_t)wave * (2u * cap + 64u * 12u + 128u);
     unsigned long long sig = 0ull;
-    const LaneJob J = lane_job(P, wave, lane);
-    if (!PROF && !J.wave_has_work) return;
+    WaveWork w;
+    w.ltile = 0u; w.s_begin = 0u; w.x0 = 0u; w.y0 = 0u; w.cols = 0u; w.n_valid = 0u; w.next = 0u; w.total = 0u;
+    bool queue_empty = false;
     const uint32_t k0 = P.key0, k1 = P.key1;
     const int threshold = (int)P.shade_threshold;
 
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
-    bool alive = false, done = s >= J.s_end, have_hit = false, overflow = false;
+    uint32_t ps = 0u, ltile = 0u; // the item (sample, pixel) and the local tile this lane's path belongs to
+    bool alive = false, done = false, have_hit = false, overflow = false;
     Rng g;
     rng_init(g, 0, 0);
     Path pa;
@@ -168,14 +164,17 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     for (;;) {
         // ================= phase A =================
         for (;;) {
-            const bool need = !have_hit && !done;
-            if (__ballot(need) == 0ull) break;
-            prof_tick<PROF>(prof, 0, need);
+            if (__ballot(!have_hit && !done) == 0ull) break;
             prof_time<PROF>(prof, 31, tstamp); // loop overhead / phase switching
-            if (need && !alive) {
-                camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
-                alive = true;
+            { // lanes whose path ended take the next (sample, pixel) item of the chunk
+                const bool want = !have_hit && !done && !alive;
+                if (__ballot(want) != 0ull) {
+                    if (work_take(w, queue_empty, want, cam, P, g, k0, k1, ps, ltile, pa)) alive = true;
+                    else if (want) done = true;
+                }
             }
+            const bool need = !have_hit && !done;
+            prof_tick<PROF>(prof, 0, need);
             prof_time<PROF>(prof, 25, tstamp); // camera samples
             RayF W;
             W.o = pa.ro; W.d = pa.rd;
@@ -214,9 +213,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     have_hit = true;
                 } else { // miss: black background (color.rs:21)
                     if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
-                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
-                    s++; alive = false;
-                    done = s >= J.s_end;
+                    path_end(P, ltile, ps, pa);
+                    if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (ps & 63u), sig); sig = 0ull; }
+                    alive = false;
                 }
             }
             if (__popcll(__ballot(have_hit)) >= threshold) break;
@@ -228,9 +227,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             have_hit = false;
             if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
             if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
-                acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
-                s++; alive = false;
-                done = s >= J.s_end;
+                path_end(P, ltile, ps, pa);
+                if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (ps & 63u), sig); sig = 0ull; }
+                alive = false;
             }
         }
         prof_time<PROF>(prof, 30, tstamp); // shading
@@ -240,11 +239,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     if (PROF) {
         __syncthreads();
         if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
-        if (!J.wave_has_work) return;
     }
-    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
-    out[0] = acc0; out[64] = acc1; out[128] = acc2;
-    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig);
 }
 
 // ----------------------------------------------------------------------------------
@@ -266,8 +261,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
 enum { ST_ITEM = 0, ST_NODE = 1, ST_PRIM = 2, ST_SHADE = 3, ST_NEW = 4, ST_DONE = 5 };
 
 template <bool FAST, bool SIG, bool PROF>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevScene sc, DevCamera cam, DevParams P,
-                                                                          double *__restrict__ partial) {
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevScene sc, DevCamera cam, DevParams P) {
     __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
     unsigned long long *prof = prof_lds;
     if (PROF) {
@@ -281,13 +275,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
     uint32_t *stack = lds_dyn + (size_t)wave * 2u * SD * 64u + lane;
     float *stack_t = reinterpret_cast<float *>(stack + SD * 64u);
     unsigned long long sig = 0ull;
-    const LaneJob J = lane_job(P, wave, lane);
-    if (!PROF && !J.wave_has_work) return;
+    const WaveWork w = wave_work(P, blockIdx.x * WAVES_PER_BLOCK + (uint32_t)wave); // one unit per wavefront, no queue
+    if (!PROF && w.total == 0u) return;
     const uint32_t k0 = P.key0, k1 = P.key1;
     const int n_items = (int)sc.n_items;
 
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
-    uint32_t s = (J.in_image && J.wave_has_work) ? J.s_begin : J.s_end;
+    // static assignment lane = pixel (this kernel predates the dynamic hand-out of the two-phase kernels)
+    const bool in_image = w.total != 0u && (uint32_t)(lane & 7) < w.cols && (uint32_t)(lane >> 3) * w.cols < w.n_valid;
+    const uint32_t s_end = in_image ? w.s_begin + w.total / w.n_valid : w.s_begin;
+    uint32_t s = w.s_begin;
     Rng g;
     rng_init(g, 0, 0);
     Path pa;
@@ -423,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                         if (best_item >= 0) { st = ST_SHADE; }
                         else { // miss: black background (color.rs:21)
                             if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
-                            acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                            path_end(P, w.ltile, (s << 6) | (uint32_t)lane, pa);
                             s++; st = ST_NEW;
                         }
                         break;
@@ -479,15 +475,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                     it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;
                     st = ST_ITEM;
                 } else {
-                    acc0 += (double)pa.L.x; acc1 += (double)pa.L.y; acc2 += (double)pa.L.z;
+                    path_end(P, w.ltile, (s << 6) | (uint32_t)lane, pa);
                     s++; st = ST_NEW;
                 }
             }
         } else { // ST_NEW
             if (st == ST_NEW) {
-                if (s >= J.s_end) { st = ST_DONE; }
+                if (s >= s_end) { st = ST_DONE; }
                 else {
-                    camera_sample(cam, P, g, k0, k1, s, J.pixel, J.px, J.j, pa);
+                    path_begin(cam, P, w, g, k0, k1, (s << 6) | (uint32_t)lane, pa);
                     W.o = pa.ro; W.d = pa.rd;
                     ray_derive(W);
                     it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;
@@ -500,25 +496,42 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
     if (PROF) {
         __syncthreads();
         if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
-        if (!J.wave_has_work) return;
     }
-    double *out = partial + ((size_t)J.item * 3) * 64 + lane;
-    out[0] = acc0; out[64] = acc1; out[128] = acc2;
-    if (SIG && J.in_image) atomicAdd(P.path_sig + (size_t)J.ltile * 64 + lane, sig);
+    if (SIG && in_image) atomicAdd(P.path_sig + (size_t)w.ltile * 64 + lane, sig); // integer add: order-independent
 }
 
-// `col /= ns; sqrt; clamp; (255.99*c) as i32` — tests/test.rs:71-78, per local texel.
-// Chunk partial sums are added in chunk order (deterministic).
-__global__ void rtmi_resolve_kernel(const double *__restrict__ partial, rtmi_texel *__restrict__ out, DevParams P) {
+// `col += color(..)` in sample order, then `col /= ns; sqrt; clamp; (255.99*c) as i32` — tests/test.rs:69-78,
+// per local texel.  One thread per (local tile, pixel): adds this pass's samples to the f64 sum (`acc`, carried
+// between passes when the per-sample buffer does not hold all ns samples at once) and, on the last pass, writes
+// the texel.  A wavefront reads 1 KB contiguous per sample.
+__global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restrict__ samples, double *__restrict__ acc,
+                                                           rtmi_texel *__restrict__ out, DevParams P, int first, int last) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= P.ntiles_local * 64u) return;
     const uint32_t ltile = tid >> 6, lane = tid & 63u;
+    const uint32_t tile = ltile * P.tile_world + P.tile_rank;
+    const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+    const bool in_image = tx * RTMI_TILE + (lane & 7u) < P.nx && ty * RTMI_TILE + (lane >> 3) < P.ny;
     double sum[3] = {0.0, 0.0, 0.0};
-    for (uint32_t c = 0; c < P.nchunks; c++) {
-        const double *src = partial + ((size_t)(c * P.ntiles_local + ltile) * 3) * 64 + lane;
-        sum[0] += src[0]; sum[1] += src[64]; sum[2] += src[128];
+    double *a = acc + ((size_t)ltile * 3) * 64 + lane;
+    if (!first) { sum[0] = a[0]; sum[1] = a[64]; sum[2] = a[128]; }
+    if (in_image) {
+        const float4 *src = samples + ((size_t)ltile * P.pass_stride) * 64u + lane;
+        uint32_t s = 0;
+        for (; s + 8u <= P.pass_cnt; s += 8u) { // 8 independent loads in flight, additions in sample order
+            float4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = src[(size_t)(s + k) * 64u];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { sum[0] += (double)v[k].x; sum[1] += (double)v[k].y; sum[2] += (double)v[k].z; }
+        }
+        for (; s < P.pass_cnt; s++) {
+            const float4 v = src[(size_t)s * 64u];
+            sum[0] += (double)v.x; sum[1] += (double)v.y; sum[2] += (double)v.z;
+        }
     }
-    rtmi_texel tx;
+    if (!last) { a[0] = sum[0]; a[64] = sum[1]; a[128] = sum[2]; return; }
+    rtmi_texel tx_out;
     uint32_t q[3];
     float lin[3];
 #pragma unroll
@@ -530,9 +543,9 @@ __global__ void rtmi_resolve_kernel(const double *__restrict__ partial, rtmi_tex
         const double x = 255.99 * g;
         q[ch] = (x != x) ? 0u : (uint32_t)(int32_t)x; // `as i32`; in [0,255] after the clamp
     }
-    tx.r = lin[0]; tx.g = lin[1]; tx.b = lin[2];
-    tx.rgb8 = q[0] | (q[1] << 8) | (q[2] << 16);
-    out[tid] = tx;
+    tx_out.r = lin[0]; tx_out.g = lin[1]; tx_out.b = lin[2];
+    tx_out.rgb8 = q[0] | (q[1] << 8) | (q[2] << 16);
+    out[tid] = tx_out;
 }
 
 // ---- device evaluation of the arithmetic contract, for parity tests --------------------

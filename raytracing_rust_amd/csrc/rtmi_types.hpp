@@ -57,12 +57,16 @@ struct DevParams {
     uint32_t nx, ny, ns, max_depth;
     float t_min;
     uint32_t key0, key1;
-    uint32_t tile_rank, tile_world, tiles_x, ntiles_local, nchunks;
+    uint32_t tile_rank, tile_world, tiles_x, ntiles_local;
+    uint32_t nchunks, chunk_spp;               // sample chunks of this pass: chunk c = [pass_s0 + c*chunk_spp, ..)
+    uint32_t pass_s0, pass_cnt, pass_stride;   // this launch renders samples [pass_s0, pass_s0 + pass_cnt)
+    float4 *samples;                           // [local tile][pass_stride][64] radiance of every finished path
     unsigned long long *path_sig;
     unsigned long long *prof;
     uint32_t stack_depth;
     uint32_t shade_threshold;
     uint32_t coop_cap;
     unsigned int *status;
+    unsigned int *queue; // next unit of the persistent wavefronts (zeroed before every launch)
     uint32_t sky; // RTMI_FLAG_SKY
 };

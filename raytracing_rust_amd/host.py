@@ -55,12 +55,13 @@ class _List(_Obj):
 
 
 def default_params(nx, ny, ns, seed=42, flags=0, max_depth=50, t_min=0.001, tile_rank=0, tile_world=1, spp_chunks=0,
-                   shade_threshold=0):
+                   shade_threshold=0, sample_buffer_bytes=0):
     p = abi.RenderParams()
     p.nx, p.ny, p.ns = nx, ny, ns
     p.max_depth, p.t_min, p.flags, p.seed = max_depth, t_min, flags, seed
     p.tile_rank, p.tile_world, p.spp_chunks = tile_rank, tile_world, spp_chunks
     p.shade_threshold = shade_threshold
+    p.sample_buffer_bytes = sample_buffer_bytes
     return p
 
 
