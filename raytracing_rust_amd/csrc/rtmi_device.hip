@@ -264,7 +264,8 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     // 288 GB of HBM the whole sample range normally fits (headline: 33 GB); otherwise the range is rendered
     // in passes and the f64 sums are carried between them — the same additions in the same order.
     const size_t per_sample = (size_t)P.ntiles_local * 64 * sizeof(float4);
-    const size_t want = p->sample_buffer_bytes ? (size_t)p->sample_buffer_bytes : ((size_t)48 << 30);
+    size_t want = p->sample_buffer_bytes ? (size_t)p->sample_buffer_bytes : ((size_t)48 << 30);
+    if (want > ((size_t)60 << 30)) want = (size_t)60 << 30; // slots are addressed with 32 bits (< 2^32 x 16 B)
     uint64_t max_pass = want / per_sample;
     if (max_pass < 1) max_pass = 1;
     if (max_pass > p->ns) max_pass = p->ns;
@@ -298,7 +299,8 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     }
     if (chunk_spp > max_pass) chunk_spp = (uint32_t)max_pass;
     if (chunk_spp < 1u) chunk_spp = 1u;
-    const uint32_t pass_ns = (uint32_t)(max_pass / chunk_spp) * chunk_spp; // whole chunks per pass
+    // one pass when everything fits (its last chunk may be shorter); otherwise whole chunks per pass
+    const uint32_t pass_ns = max_pass >= p->ns ? p->ns : (uint32_t)(max_pass / chunk_spp) * chunk_spp;
     P.chunk_spp = chunk_spp;
     P.pass_stride = pass_ns;
     P.samples = s->samples;

@@ -32,12 +32,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
     uint32_t *stack = &lds_stack[wave][0][0][lane];
     unsigned long long sig = 0ull;
     WaveWork w;
-    w.ltile = 0u; w.s_begin = 0u; w.x0 = 0u; w.y0 = 0u; w.cols = 0u; w.n_valid = 0u; w.next = 0u; w.total = 0u;
+    w.ltile = 0u; w.ps_base = 0u; w.obase = 0u; w.x0 = 0u; w.y0 = 0u; w.cols = 0u; w.n_valid = 0u; w.next = 0u; w.total = 0u;
     bool queue_empty = false;
     const uint32_t k0 = P.key0, k1 = P.key1;
     const int threshold = (int)P.shade_threshold;
 
-    uint32_t ps = 0u, ltile = 0u; // the item (sample, pixel) and the local tile this lane's path belongs to
+    uint32_t oidx = 0u, ltile = 0u; // slot of this lane's path in the per-sample buffer; its local tile (SIG only)
     bool alive = false, done = false, have_hit = false;
     Rng g;
     rng_init(g, 0, 0);
@@ -54,8 +54,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
             { // lanes whose path ended take the next (sample, pixel) item of the chunk
                 const bool want = !have_hit && !done && !alive;
                 if (__ballot(want) != 0ull) {
-                    if (work_take(w, queue_empty, want, cam, P, g, k0, k1, ps, ltile, pa)) alive = true;
-                    else if (want) done = true;
+                    uint32_t smp = 0u, px = 0u, j = 0u;
+                    if (work_take(w, queue_empty, want, P, oidx, ltile, smp, px, j)) {
+                        camera_sample(cam, P, g, k0, k1, smp, j * P.nx + px, px, j, pa);
+                        alive = true;
+                    } else if (want) {
+                        done = true;
+                    }
                 }
             }
             const bool need = !have_hit && !done;
@@ -97,8 +102,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                     have_hit = true;
                 } else { // miss: black background (color.rs:21); the path ends
                     if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
-                    path_end(P, ltile, ps, pa);
-                    if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (ps & 63u), sig); sig = 0ull; }
+                    path_end(P, oidx, pa);
+                    if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
                     alive = false;
                 }
             }
@@ -112,8 +117,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
             if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
             if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
                 // absorbed, emitter or depth limit: the path ends
-                path_end(P, ltile, ps, pa);
-                if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (ps & 63u), sig); sig = 0ull; }
+                path_end(P, oidx, pa);
+                if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
                 alive = false;
             }
         }
@@ -145,12 +150,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     uint32_t *wlds = lds_dyn + (size_t)wave * (2u * cap + 64u * 12u + 128u);
     unsigned long long sig = 0ull;
     WaveWork w;
-    w.ltile = 0u; w.s_begin = 0u; w.x0 = 0u; w.y0 = 0u; w.cols = 0u; w.n_valid = 0u; w.next = 0u; w.total = 0u;
+    w.ltile = 0u; w.ps_base = 0u; w.obase = 0u; w.x0 = 0u; w.y0 = 0u; w.cols = 0u; w.n_valid = 0u; w.next = 0u; w.total = 0u;
     bool queue_empty = false;
     const uint32_t k0 = P.key0, k1 = P.key1;
     const int threshold = (int)P.shade_threshold;
 
-    uint32_t ps = 0u, ltile = 0u; // the item (sample, pixel) and the local tile this lane's path belongs to
+    uint32_t oidx = 0u, ltile = 0u; // slot of this lane's path in the per-sample buffer; its local tile (SIG only)
     bool alive = false, done = false, have_hit = false, overflow = false;
     Rng g;
     rng_init(g, 0, 0);
@@ -169,8 +174,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             { // lanes whose path ended take the next (sample, pixel) item of the chunk
                 const bool want = !have_hit && !done && !alive;
                 if (__ballot(want) != 0ull) {
-                    if (work_take(w, queue_empty, want, cam, P, g, k0, k1, ps, ltile, pa)) alive = true;
-                    else if (want) done = true;
+                    uint32_t smp = 0u, px = 0u, j = 0u;
+                    if (work_take(w, queue_empty, want, P, oidx, ltile, smp, px, j)) {
+                        camera_sample(cam, P, g, k0, k1, smp, j * P.nx + px, px, j, pa);
+                        alive = true;
+                    } else if (want) {
+                        done = true;
+                    }
                 }
             }
             const bool need = !have_hit && !done;
@@ -213,8 +223,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     have_hit = true;
                 } else { // miss: black background (color.rs:21)
                     if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
-                    path_end(P, ltile, ps, pa);
-                    if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (ps & 63u), sig); sig = 0ull; }
+                    path_end(P, oidx, pa);
+                    if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
                     alive = false;
                 }
             }
@@ -227,8 +237,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             have_hit = false;
             if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
             if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
-                path_end(P, ltile, ps, pa);
-                if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (ps & 63u), sig); sig = 0ull; }
+                path_end(P, oidx, pa);
+                if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
                 alive = false;
             }
         }
@@ -282,8 +292,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
 
     // static assignment lane = pixel (this kernel predates the dynamic hand-out of the two-phase kernels)
     const bool in_image = w.total != 0u && (uint32_t)(lane & 7) < w.cols && (uint32_t)(lane >> 3) * w.cols < w.n_valid;
-    const uint32_t s_end = in_image ? w.s_begin + w.total / w.n_valid : w.s_begin;
-    uint32_t s = w.s_begin;
+    const uint32_t s_begin = w.ps_base >> 6;
+    const uint32_t s_end = in_image ? s_begin + w.total / w.n_valid : s_begin;
+    const uint32_t px = w.x0 + (uint32_t)(lane & 7), j = P.ny - 1u - (w.y0 + (uint32_t)(lane >> 3));
+    uint32_t s = s_begin;
     Rng g;
     rng_init(g, 0, 0);
     Path pa;
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                         if (best_item >= 0) { st = ST_SHADE; }
                         else { // miss: black background (color.rs:21)
                             if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
-                            path_end(P, w.ltile, (s << 6) | (uint32_t)lane, pa);
+                            path_end(P, w.obase + ((s << 6) | (uint32_t)lane), pa);
                             s++; st = ST_NEW;
                         }
                         break;
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                     it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;
                     st = ST_ITEM;
                 } else {
-                    path_end(P, w.ltile, (s << 6) | (uint32_t)lane, pa);
+                    path_end(P, w.obase + ((s << 6) | (uint32_t)lane), pa);
                     s++; st = ST_NEW;
                 }
             }
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
             if (st == ST_NEW) {
                 if (s >= s_end) { st = ST_DONE; }
                 else {
-                    path_begin(cam, P, w, g, k0, k1, (s << 6) | (uint32_t)lane, pa);
+                    camera_sample(cam, P, g, k0, k1, s, j * P.nx + px, px, j, pa);
                     W.o = pa.ro; W.d = pa.rd;
                     ray_derive(W);
                     it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;

@@ -307,86 +307,80 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
 // the resolve kernel adds them in sample order (tests/test.rs:65-70), so the result does not
 // depend on which lane rendered what, nor on chunking or scheduling.
 // ----------------------------------------------------------------------------------
-struct WaveWork { // wave-uniform
-    uint32_t ltile, s_begin, x0, y0, cols, n_valid, next, total;
+struct WaveWork { // wave-uniform (kept in SGPRs: every field passes through readfirstlane)
+    uint32_t ltile, ps_base, obase, x0, y0, cols, n_valid, next, total;
 };
+__device__ __forceinline__ uint32_t rfl(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ WaveWork wave_work(const DevParams &P, uint32_t unit) {
     WaveWork w;
     const bool has_work = unit < P.ntiles_local * P.nchunks;
     const uint32_t chunk = unit / P.ntiles_local; // chunk-major: all tiles of chunk 0 first
-    w.ltile = unit - chunk * P.ntiles_local;
-    const uint32_t tile = w.ltile * P.tile_world + P.tile_rank;
+    const uint32_t ltile = unit - chunk * P.ntiles_local;
+    const uint32_t tile = ltile * P.tile_world + P.tile_rank;
     const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-    w.x0 = tx * RTMI_TILE;
-    w.y0 = ty * RTMI_TILE;
-    const uint32_t cols = w.x0 < P.nx ? (P.nx - w.x0 < RTMI_TILE ? P.nx - w.x0 : RTMI_TILE) : 0u;
-    const uint32_t rows = w.y0 < P.ny ? (P.ny - w.y0 < RTMI_TILE ? P.ny - w.y0 : RTMI_TILE) : 0u;
-    w.cols = cols;
-    w.n_valid = cols * rows;
-    w.s_begin = P.pass_s0 + chunk * P.chunk_spp;
+    const uint32_t x0 = tx * RTMI_TILE, y0 = ty * RTMI_TILE;
+    const uint32_t cols = x0 < P.nx ? (P.nx - x0 < RTMI_TILE ? P.nx - x0 : RTMI_TILE) : 0u;
+    const uint32_t rows = y0 < P.ny ? (P.ny - y0 < RTMI_TILE ? P.ny - y0 : RTMI_TILE) : 0u;
+    const uint32_t s_begin = P.pass_s0 + chunk * P.chunk_spp;
     const uint32_t pass_end = P.pass_s0 + P.pass_cnt;
-    uint32_t s_end = w.s_begin + P.chunk_spp;
+    uint32_t s_end = s_begin + P.chunk_spp;
     if (s_end > pass_end) s_end = pass_end;
-    w.total = (has_work && s_end > w.s_begin) ? (s_end - w.s_begin) * w.n_valid : 0u;
+    w.ltile = rfl(ltile);
+    w.x0 = rfl(x0);
+    w.y0 = rfl(y0);
+    w.cols = rfl(cols);
+    w.n_valid = rfl(cols * rows);
+    w.ps_base = rfl(s_begin << 6);
+    // slot of item ps = sample << 6 | pixel in the per-sample buffer: (ltile * stride + sample - pass_s0) * 64 + pixel
+    // = obase + ps in uint32 arithmetic (the host keeps the buffer below 2^32 slots)
+    w.obase = rfl((ltile * P.pass_stride - P.pass_s0) * 64u);
+    w.total = rfl((has_work && s_end > s_begin) ? (s_end - s_begin) * cols * rows : 0u);
     w.next = 0u;
     return w;
 }
-// All 64 lanes call this together; every lane with want = true receives the next item (true) or learns
-// that the chunk is exhausted (false).  ps = sample << 6 | pixel-in-tile (row * 8 + column).
-__device__ __forceinline__ bool work_draw(WaveWork &w, bool want, uint32_t &ps) {
-    const unsigned long long m = __ballot(want);
-    const uint32_t k = w.next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    w.next += (uint32_t)__popcll(m);
-    const bool ok = want && k < w.total;
-    if (ok) {
-        if (w.n_valid == 64u) { // wave-uniform
-            ps = ((w.s_begin + (k >> 6)) << 6) | (k & 63u);
-        } else { // ragged tile on the right / bottom edge: a cols x rows rectangle of the 8x8 tile
-            const uint32_t ds = k / w.n_valid, idx = k - ds * w.n_valid;
-            const uint32_t row = idx / w.cols, col = idx - row * w.cols;
-            ps = ((w.s_begin + ds) << 6) | (row * RTMI_TILE + col);
-        }
-    }
-    return ok;
-}
-// Persistent wavefront: every lane with want = true receives an item (ps, and the local tile it belongs
-// to) and starts its path, from the current unit or, when that is exhausted, from the next units of the
-// global queue.  Returns false for lanes that wanted but found the queue empty: they are done for good.
-// The loop ends for every wavefront: the counter only grows and nunits is fixed.
-__device__ __forceinline__ void path_begin(const DevCamera &cam, const DevParams &P, const WaveWork &w, Rng &g, uint32_t k0,
-                                           uint32_t k1, uint32_t ps, Path &pa);
-__device__ __forceinline__ bool work_take(WaveWork &w, bool &queue_empty, bool want, const DevCamera &cam,
-                                          const DevParams &P, Rng &g, uint32_t k0, uint32_t k1, uint32_t &ps,
-                                          uint32_t &ltile, Path &pa) {
+// Persistent wavefront; all 64 lanes call this together.  Every lane with want = true receives the next item
+// (sample s of pixel (px, j) of local tile ltile; oidx = its slot in the per-sample buffer) from the current
+// unit or, when that is exhausted, from the next units of the global queue.  Returns false for lanes that
+// wanted but found the queue empty: they are done for good.  The loop ends for every wavefront: the
+// counter only grows and the number of units is fixed.
+__device__ __forceinline__ bool work_take(WaveWork &w, bool &queue_empty, bool want, const DevParams &P, uint32_t &oidx,
+                                          uint32_t &ltile, uint32_t &smp, uint32_t &px, uint32_t &j) {
     bool got = false;
     for (;;) {
         const bool still = want && !got;
-        if (__ballot(still) == 0ull) break;
+        const unsigned long long m = __ballot(still);
+        if (m == 0ull) break;
         if (w.next >= w.total) { // wave-uniform: unit exhausted, take the next one
             if (queue_empty) break;
             uint32_t u = 0u;
             if ((threadIdx.x & 63) == 0) u = atomicAdd(P.queue, 1u);
-            u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+            u = rfl(u);
             if (u >= P.ntiles_local * P.nchunks) { queue_empty = true; break; }
             w = wave_work(P, u);
             continue;
         }
-        if (work_draw(w, still, ps)) {
+        const uint32_t k = w.next + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        w.next = rfl(w.next + (uint32_t)__popcll(m));
+        if (still && k < w.total) {
+            uint32_t ps; // sample << 6 | pixel-in-tile (row * 8 + column)
+            if (w.n_valid == 64u) { // wave-uniform: items are sample-major, 64 pixels per sample
+                ps = w.ps_base + k;
+            } else { // ragged tile on the right / bottom edge: a cols x rows rectangle of the 8x8 tile
+                const uint32_t ds = k / w.n_valid, idx = k - ds * w.n_valid;
+                const uint32_t row = idx / w.cols, col = idx - row * w.cols;
+                ps = w.ps_base + (ds << 6) + (row * RTMI_TILE + col);
+            }
+            oidx = w.obase + ps;
             ltile = w.ltile;
-            path_begin(cam, P, w, g, k0, k1, ps, pa);
+            smp = ps >> 6;
+            px = w.x0 + (ps & 7u);
+            j = P.ny - 1u - (w.y0 + ((ps >> 3) & 7u)); // `for j in (0..ny).rev()` — tests/test.rs:62
             got = true;
         }
     }
     return got;
 }
-// first sample of the path `ps` of this wave's tile: pixel coordinates, RNG stream, camera ray
-__device__ __forceinline__ void path_begin(const DevCamera &cam, const DevParams &P, const WaveWork &w, Rng &g, uint32_t k0,
-                                           uint32_t k1, uint32_t ps, Path &pa) {
-    const uint32_t px = w.x0 + (ps & 7u);
-    const uint32_t j = P.ny - 1u - (w.y0 + ((ps >> 3) & 7u)); // `for j in (0..ny).rev()` — tests/test.rs:62
-    camera_sample(cam, P, g, k0, k1, ps >> 6, j * P.nx + px, px, j, pa);
-}
 // `col += color(..)` — tests/test.rs:69: the path's radiance goes to its slot of the per-sample buffer
-__device__ __forceinline__ void path_end(const DevParams &P, uint32_t ltile, uint32_t ps, const Path &pa) {
-    P.samples[((size_t)ltile * P.pass_stride + ((ps >> 6) - P.pass_s0)) * 64u + (ps & 63u)] = make_float4(pa.L.x, pa.L.y, pa.L.z, 0.0f);
+__device__ __forceinline__ void path_end(const DevParams &P, uint32_t oidx, const Path &pa) {
+    P.samples[oidx] = make_float4(pa.L.x, pa.L.y, pa.L.z, 0.0f);
 }
