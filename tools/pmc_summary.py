@@ -17,6 +17,7 @@ import sys
 
 def per_kernel(tag_dir, counter):
     files = glob.glob(os.path.join(tag_dir, "pmc_" + counter, "**", "*counter_collection.csv"), recursive=True)
+    files = sorted(files, key=os.path.getmtime)[-1:]  # gpurun merges into existing directories: newest run only
     out = {}
     for f in files:
         for row in csv.DictReader(open(f)):
