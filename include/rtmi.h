@@ -219,6 +219,11 @@ void rtmi_scene_destroy(rtmi_scene *scene);
  * tile = ty * tiles_x + tx counted from the TOP-left tile. */
 uint32_t rtmi_local_tiles(const rtmi_render_params *p);
 
+/* Optional: allocate everything a later rtmi_render_device/rtmi_render call with the same params needs (the
+ * per-sample radiance buffer, 16 B x local pixels x samples per pass, and the f64 sums), so that the first
+ * render call does not pay for the allocation.  Idempotent; render calls allocate on demand anyway. */
+int rtmi_render_prepare(rtmi_scene *scene, const rtmi_render_params *params);
+
 /* Enqueues the render on `stream` (a hipStream_t, may be NULL) and writes
  * rtmi_local_tiles()*64 texels to the DEVICE buffer d_texels.  Does not synchronise
  * unless `stats` is non-NULL (then it waits for the kernels to fill kernel_ms). */

@@ -102,7 +102,7 @@ class Stats(C.Structure):
 
 # every entry point include/rtmi.h declares (tests check that the library exports them all)
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_local_tiles",
-                "rtmi_render_device", "rtmi_render", "rtmi_untile", "rtmi_ppm_p3", "rtmi_probe_math",
+                "rtmi_render_prepare", "rtmi_render_device", "rtmi_render", "rtmi_untile", "rtmi_ppm_p3", "rtmi_probe_math",
                 "rtmi_probe_philox"]
 
 _rtmi = None
@@ -190,6 +190,7 @@ def load_host():
         "rth_upload": (i, [vp, i]),
         "rth_render": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]),
         "rth_render_device": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]),
+        "rth_render_prepare": (i, [vp, C.POINTER(RenderParams)]),
         "rth_camera_render": (i, [vp, vp, u32, u32, u32, u64, u32, i, vp, vp, C.POINTER(Stats)]),
         "rth_hit": (i, [vp, vp, vp, d, d, d, u64, vp, vp]),
         "rth_bounding_box": (i, [vp, d, d, vp, vp]),

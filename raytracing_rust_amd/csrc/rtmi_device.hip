@@ -236,6 +236,71 @@ static int check_params(const rtmi_render_params *p) {
     return RTMI_OK;
 }
 
+// Plan of one render call: unit size, samples per pass; (re)allocates the per-sample buffer and the f64 sums.
+static int plan_and_reserve(rtmi_scene *s, const rtmi_render_params *p, uint32_t ntiles_local, uint32_t &chunk_spp,
+                            uint32_t &pass_ns) {
+    // ---- per-sample buffer and passes.  Every finished path stores its radiance (16 B) in
+    // samples[local tile][sample of the pass][pixel]; the resolve kernel adds them in sample order.  With
+    // 288 GB of HBM the whole sample range normally fits (headline: 33 GB); otherwise the range is rendered
+    // in passes and the f64 sums are carried between them — the same additions in the same order.
+    const size_t per_sample = (size_t)ntiles_local * 64 * sizeof(float4);
+    size_t want = p->sample_buffer_bytes ? (size_t)p->sample_buffer_bytes : ((size_t)48 << 30);
+    if (want > ((size_t)60 << 30)) want = (size_t)60 << 30; // slots are addressed with 32 bits (< 2^32 x 16 B)
+    uint64_t max_pass = want / per_sample;
+    if (max_pass < 1) max_pass = 1;
+    if (max_pass > p->ns) max_pass = p->ns;
+    if (max_pass * per_sample > s->samples_bytes) {
+        if (!p->sample_buffer_bytes) { // default budget: never more than 3/4 of what is free on the device
+            size_t free_b = 0, total_b = 0;
+            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+            const size_t avail = (free_b + s->samples_bytes) / 4 * 3;
+            if (max_pass * per_sample > avail) max_pass = avail / per_sample ? avail / per_sample : 1;
+        }
+        if (max_pass * per_sample > s->samples_bytes) {
+            if (s->samples) { HIP_TRY(hipFree(s->samples)); s->samples = nullptr; s->samples_bytes = 0; }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->samples), max_pass * per_sample));
+            s->samples_bytes = max_pass * per_sample;
+        }
+    }
+    // unit = (tile, chunk of the sample range), the grain of the persistent wavefronts' queue.  Lanes
+    // take (sample, pixel) items dynamically and a wavefront moves on to the next unit without
+    // draining, so units can be small: the launch ends within about one heavy unit of the last
+    // wavefront.  Small images still get a few units per wavefront slot.
+    if (p->spp_chunks) {
+        chunk_spp = (p->ns + p->spp_chunks - 1) / p->spp_chunks;
+    } else {
+        chunk_spp = 16u;
+        const uint64_t want_units = (uint64_t)s->slots * 4u;
+        if ((uint64_t)ntiles_local * ((p->ns + chunk_spp - 1) / chunk_spp) < want_units) {
+            const uint64_t per_tile = (want_units + ntiles_local - 1) / ntiles_local;
+            chunk_spp = (uint32_t)((p->ns + per_tile - 1) / per_tile);
+        }
+    }
+    if (chunk_spp > max_pass) chunk_spp = (uint32_t)max_pass;
+    if (chunk_spp < 1u) chunk_spp = 1u;
+    // one pass when everything fits (its last chunk may be shorter); otherwise whole chunks per pass
+    pass_ns = max_pass >= p->ns ? p->ns : (uint32_t)(max_pass / chunk_spp) * chunk_spp;
+
+    const size_t need = (size_t)ntiles_local * 64 * 3 * sizeof(double); // f64 sums carried between passes
+    if (need > s->partial_bytes) {
+        if (s->partial) { HIP_TRY(hipFree(s->partial)); s->partial = nullptr; s->partial_bytes = 0; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->partial), need));
+        s->partial_bytes = need;
+    }
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_render_prepare(rtmi_scene *s, const rtmi_render_params *p) {
+    if (!s) return fail(RTMI_ERR_INVALID, "NULL argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t ntiles_local = local_tiles_of(p, p->tile_rank);
+    if (ntiles_local == 0) return RTMI_OK;
+    uint32_t chunk_spp = 0, pass_ns = 0;
+    return plan_and_reserve(s, p, ntiles_local, chunk_spp, pass_ns);
+}
+
 extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p, void *d_texels,
                                   void *stream_, rtmi_stats *stats) {
     if (!s || !cam || !d_texels) return fail(RTMI_ERR_INVALID, "NULL argument");
@@ -259,58 +324,12 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
         HIP_TRY(hipMemsetAsync(P.path_sig, 0, (size_t)P.ntiles_local * 64 * sizeof(unsigned long long), stream));
     }
 
-    // ---- per-sample buffer and passes.  Every finished path stores its radiance (16 B) in
-    // samples[local tile][sample of the pass][pixel]; the resolve kernel adds them in sample order.  With
-    // 288 GB of HBM the whole sample range normally fits (headline: 33 GB); otherwise the range is rendered
-    // in passes and the f64 sums are carried between them — the same additions in the same order.
-    const size_t per_sample = (size_t)P.ntiles_local * 64 * sizeof(float4);
-    size_t want = p->sample_buffer_bytes ? (size_t)p->sample_buffer_bytes : ((size_t)48 << 30);
-    if (want > ((size_t)60 << 30)) want = (size_t)60 << 30; // slots are addressed with 32 bits (< 2^32 x 16 B)
-    uint64_t max_pass = want / per_sample;
-    if (max_pass < 1) max_pass = 1;
-    if (max_pass > p->ns) max_pass = p->ns;
-    if (max_pass * per_sample > s->samples_bytes) {
-        if (!p->sample_buffer_bytes) { // default budget: never more than 3/4 of what is free on the device
-            size_t free_b = 0, total_b = 0;
-            HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const size_t avail = (free_b + s->samples_bytes) / 4 * 3;
-            if (max_pass * per_sample > avail) max_pass = avail / per_sample ? avail / per_sample : 1;
-        }
-        if (max_pass * per_sample > s->samples_bytes) {
-            if (s->samples) { HIP_TRY(hipFree(s->samples)); s->samples = nullptr; s->samples_bytes = 0; }
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->samples), max_pass * per_sample));
-            s->samples_bytes = max_pass * per_sample;
-        }
-    }
-    // unit = (tile, chunk of the sample range), the grain of the persistent wavefronts' queue.  Lanes
-    // take (sample, pixel) items dynamically and a wavefront moves on to the next unit without
-    // draining, so units can be small: the launch ends within about one heavy unit of the last
-    // wavefront.  Small images still get a few units per wavefront slot.
-    uint32_t chunk_spp;
-    if (p->spp_chunks) {
-        chunk_spp = (p->ns + p->spp_chunks - 1) / p->spp_chunks;
-    } else {
-        chunk_spp = 16u;
-        const uint64_t want_units = (uint64_t)s->slots * 4u;
-        if ((uint64_t)P.ntiles_local * ((p->ns + chunk_spp - 1) / chunk_spp) < want_units) {
-            const uint64_t per_tile = (want_units + P.ntiles_local - 1) / P.ntiles_local;
-            chunk_spp = (uint32_t)((p->ns + per_tile - 1) / per_tile);
-        }
-    }
-    if (chunk_spp > max_pass) chunk_spp = (uint32_t)max_pass;
-    if (chunk_spp < 1u) chunk_spp = 1u;
-    // one pass when everything fits (its last chunk may be shorter); otherwise whole chunks per pass
-    const uint32_t pass_ns = max_pass >= p->ns ? p->ns : (uint32_t)(max_pass / chunk_spp) * chunk_spp;
+    uint32_t chunk_spp = 0, pass_ns = 0;
+    rc = plan_and_reserve(s, p, P.ntiles_local, chunk_spp, pass_ns);
+    if (rc) return rc;
     P.chunk_spp = chunk_spp;
     P.pass_stride = pass_ns;
     P.samples = s->samples;
-
-    const size_t need = (size_t)P.ntiles_local * 64 * 3 * sizeof(double); // f64 sums carried between passes
-    if (need > s->partial_bytes) {
-        if (s->partial) { HIP_TRY(hipFree(s->partial)); s->partial = nullptr; s->partial_bytes = 0; }
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->partial), need));
-        s->partial_bytes = need;
-    }
 
     DevCamera C;
     C.origin = F3{cam->origin[0], cam->origin[1], cam->origin[2]};

@@ -130,6 +130,11 @@ class Scene:
     def local_tiles(self, params):
         return abi.load_rtmi().rtmi_local_tiles(C.byref(params))
 
+    def prepare(self, params):
+        """Allocate the render buffers for `params` now (per-sample buffer: 16 B x local pixels x samples per pass)."""
+        self.host._check(self.host.lib.rth_render_prepare(self.h, C.byref(params)))
+        return self
+
     def render_device(self, cam, params, d_texels_ptr, stream=None, want_stats=False):
         """Enqueue on `stream`; writes rtmi_local_tiles()*64 texels (16 B) at device address d_texels_ptr."""
         st = abi.Stats() if want_stats else None

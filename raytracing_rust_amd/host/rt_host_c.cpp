@@ -250,6 +250,15 @@ RTH_API int rth_render_device(void *lowered, void *cam, const rtmi_render_params
         return RTH_OK;
     });
 }
+// allocate the render buffers for `p` ahead of the first render call (optional)
+RTH_API int rth_render_prepare(void *lowered, const rtmi_render_params *p) {
+    return guard([&] {
+        Obj *o = LOW(lowered);
+        if (!o->dev) throw std::runtime_error("scene not uploaded: call rth_upload first");
+        if (rtmi_render_prepare(o->dev, p)) throw std::runtime_error(std::string("rtmi_render_prepare: ") + rtmi_last_error());
+        return RTH_OK;
+    });
+}
 // Camera::render / create_image in one call (lower + upload + render + free)
 RTH_API int rth_camera_render(void *cam, void *world, uint32_t nx, uint32_t ny, uint32_t ns, uint64_t seed, uint32_t flags,
                               int device, float *out_linear, uint8_t *out_rgb8, rtmi_stats *stats) {

@@ -106,6 +106,13 @@ def test_result_independent_of_chunking_and_tiling(host):
         assert np.array_equal(base["rgb8"], other["rgb8"]), budget
         assert np.array_equal(base["linear"], other["linear"]), budget
     assert np.array_equal(sc.render(cam, nx, ny, ns, seed=5, sig=True)["sig"], other["sig"])
+    # every kernel variant writes the same per-sample buffer: passes and unit sizes must not matter for any of them
+    ref = sc.render(cam, nx, ny, ns, seed=5, flags=0, sig=True)
+    for flags in (0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_ASYNC,
+                  abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL):
+        other = sc.render(cam, nx, ny, ns, seed=5, flags=flags, spp_chunks=5, sample_buffer_bytes=per_sample * 4, sig=True)
+        assert np.array_equal(ref["linear"], other["linear"]), flags
+        assert np.array_equal(ref["sig"], other["sig"]), flags
     # tile sharding, emulated on one GPU: render each rank's tiles, then untile
     import torch
 
