@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 1u
+#define RTMI_ABI_VERSION 2u
 #define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
 #define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
 
@@ -127,7 +127,9 @@ typedef struct {
     int32_t medium_material; /* MEDIUM: index of the Isotropic phase material (medium.rs:19-24) */
     float neg_inv_density;   /* MEDIUM: -(1/density) (medium.rs:40) */
     float root_min[3], root_max[3]; /* BVH: bbox of the root node (bvh.rs:60-64) */
-    float scale;             /* BVH: largest |coordinate| of the root box (fast-cull margins only) */
+    float scale;             /* BVH: largest |coordinate| of the root box (fast-cull margins only); 1e30 = never prune
+                              * (a BVH whose boxes do not contain their primitives, e.g. Rect::bounding_box of a
+                              * YZ/ZX rect, rect.rs:71-75: pruned traversal then visits what BVHNode::hit visits) */
     int32_t pad;
 } rtmi_item; /* 64 B */
 
@@ -154,6 +156,10 @@ typedef struct {
     const uint8_t *image_data;
     uint64_t image_bytes;
     uint32_t max_bvh_depth; /* must be <= RTMI_MAX_BVH_DEPTH */
+    /* Ray times for which the BVH boxes contain their moving spheres (the intersection of the [time0, time1] of
+     * every MovingSphere inside a BVH; -FLT_MAX..FLT_MAX when there is none).  A camera whose shutter interval
+     * leaves this range is rendered with exact instead of pruned traversal (same image, slower). */
+    float bvh_time_lo, bvh_time_hi;
 } rtmi_scene_desc;
 
 /* Camera state (src/camera.rs:8-18), already derived by Camera::new (camera.rs:21-51) */
@@ -252,6 +258,10 @@ size_t rtmi_ppm_p3(uint32_t nx, uint32_t ny, const uint8_t *rgb8, char *buf, siz
  * 5 sqrt(x), 6 rtmi_u01(bits of x).  ctr: n*4 words, key: n*2 words, out: n*4 words. */
 int rtmi_probe_math(int op, const float *x, const float *y, float *out, uint32_t n);
 int rtmi_probe_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out, uint32_t n);
+/* Instance transforms as the render kernels apply them (src/traslate.rs:18-24, src/rotate.rs:85-113): for each of
+ * the n inputs (a, b: 3 floats each) out[13*i..] = world->object ray (origin a, direction b: 6 floats), object->world
+ * hit record (point a, normal b: 6 floats), and 1.0 when a rotation was applied.  xforms: outermost wrapper first. */
+int rtmi_probe_xform(const rtmi_xform *xforms, uint32_t count, const float *a, const float *b, float *out, uint32_t n);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import os
 
 from . import build as _build
 
-RTMI_ABI_VERSION = 1
+RTMI_ABI_VERSION = 2
 RTMI_MAX_BVH_DEPTH = 24
 RTMI_TILE = 8
 RTMI_FLAG_FAST_CULL = 1
@@ -75,7 +75,7 @@ class SceneDesc(C.Structure):
                 ("n_perlin", C.c_uint32), ("perlin", C.POINTER(Perlin)),
                 ("n_images", C.c_uint32), ("images", C.POINTER(ImageDesc)),
                 ("image_data", C.POINTER(C.c_uint8)), ("image_bytes", C.c_uint64),
-                ("max_bvh_depth", C.c_uint32)]
+                ("max_bvh_depth", C.c_uint32), ("bvh_time_lo", C.c_float), ("bvh_time_hi", C.c_float)]
 
 
 class Camera(C.Structure):
@@ -103,7 +103,7 @@ class Stats(C.Structure):
 # every entry point include/rtmi.h declares (tests check that the library exports them all)
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_local_tiles",
                 "rtmi_render_prepare", "rtmi_render_device", "rtmi_render", "rtmi_untile", "rtmi_ppm_p3", "rtmi_probe_math",
-                "rtmi_probe_philox"]
+                "rtmi_probe_philox", "rtmi_probe_xform"]
 
 _rtmi = None
 _host = None
@@ -139,6 +139,8 @@ def load_rtmi():
     lib.rtmi_probe_math.argtypes = [C.c_int, vp, vp, vp, C.c_uint32]
     lib.rtmi_probe_philox.restype = C.c_int
     lib.rtmi_probe_philox.argtypes = [vp, vp, vp, C.c_uint32]
+    lib.rtmi_probe_xform.restype = C.c_int
+    lib.rtmi_probe_xform.argtypes = [C.POINTER(Xform), C.c_uint32, vp, vp, vp, C.c_uint32]
     _rtmi = lib
     return lib
 

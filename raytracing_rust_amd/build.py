@@ -43,8 +43,12 @@ def build_rtmi(force=False, verbose=False):
     if not force and not _stale(LIBRTMI, RTMI_DEPS):
         return LIBRTMI
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-           "-I" + INCLUDE, "-o", LIBRTMI] + RTMI_SRC
+    # -fno-slp-vectorize: ROCm 7.2's SLP vectoriser packs the scalar F3 arithmetic into v_pk_mul/add_f32 and gets the
+    # operand selection wrong in at least one place (hit point/normal of a sphere under Rotate about Z: every
+    # pixel differed from the oracle, found by tests/test_random_scenes.py; fine with the function out of line,
+    # fine without SLP).  The scalar code is also 2-3 % faster on this VALU-bound path.
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+           "-std=c++17", "-I" + INCLUDE, "-o", LIBRTMI] + RTMI_SRC
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)

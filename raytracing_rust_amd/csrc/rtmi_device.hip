@@ -341,7 +341,10 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     C.time0 = cam->time0; C.time1 = cam->time1; C.lens_radius = cam->lens_radius;
 
     if (stats) HIP_TRY(hipEventRecord(s->ev[0], stream));
-    const bool fast = (p->flags & RTMI_FLAG_FAST_CULL) != 0u, sigf = (p->flags & RTMI_FLAG_PATH_SIG) != 0u;
+    // pruned traversal needs the BVH boxes to contain their moving spheres at every ray time (camera.rs:65)
+    const float cam_t_lo = cam->time0 < cam->time1 ? cam->time0 : cam->time1, cam_t_hi = cam->time0 < cam->time1 ? cam->time1 : cam->time0;
+    const bool boxes_valid = cam_t_lo >= s->meta.bvh_time_lo && cam_t_hi <= s->meta.bvh_time_hi;
+    const bool fast = (p->flags & RTMI_FLAG_FAST_CULL) != 0u && boxes_valid, sigf = (p->flags & RTMI_FLAG_PATH_SIG) != 0u;
     const dim3 block(64 * WAVES_PER_BLOCK);
     P.stack_depth = s->meta.max_bvh_depth + 1u;
     P.shade_threshold = p->shade_threshold ? (p->shade_threshold > 64u ? 64u : p->shade_threshold) : 1u;
@@ -545,6 +548,23 @@ extern "C" int rtmi_probe_math(int op, const float *x, const float *y, float *ou
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return RTMI_OK;
+}
+extern "C" int rtmi_probe_xform(const rtmi_xform *xforms, uint32_t count, const float *a, const float *b, float *out, uint32_t n) {
+    if (rtmi_device_count() <= 0) return fail(RTMI_ERR_DEVICE, "no HIP device available");
+    rtmi_xform *dx = nullptr;
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dx), (count ? count : 1) * sizeof(rtmi_xform)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&da), n * 12));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&db), n * 12));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dout), n * 13 * 4));
+    if (count) HIP_TRY(hipMemcpy(dx, xforms, count * sizeof(rtmi_xform), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(da, a, n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, b, n * 12, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rtmi_xform_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dx, (int)count, da, db, dout, n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout, n * 13 * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return RTMI_OK;
 }
 extern "C" int rtmi_probe_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out, uint32_t n) {

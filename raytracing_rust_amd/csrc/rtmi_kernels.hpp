@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restr
 }
 
 // ---- device evaluation of the arithmetic contract, for parity tests --------------------
-// op: 0 sin, 1 log, 2 atan2(x,y), 3 asin, 4 x/y, 5 sqrt, 6 u01(bits of x)
+// op: 0 sin, 1 log, 2 atan2(x,y), 3 asin, 4 x/y, 5 sqrt, 6 u01(bits of x), 16.. instance transforms
 __global__ void rtmi_math_probe_kernel(int op, const float *x, const float *y, float *out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -573,9 +573,35 @@ __global__ void rtmi_math_probe_kernel(int op, const float *x, const float *y, f
     case 3: r = rtmi_asinf(x[i]); break;
     case 4: r = x[i] / y[i]; break;
     case 5: r = __builtin_sqrtf(x[i]); break;
-    default: r = rtmi_u01(__float_as_uint(x[i])); break;
+    case 6: r = rtmi_u01(__float_as_uint(x[i])); break;
+    default: { // 16 + 4*(axis) + which: instance transforms (rotate.rs:85-113) by sin/cos of 33 degrees
+        const int axis = ((op - 16) >> 2) % 3, which = (op - 16) & 3;
+        rtmi_xform X;
+        X.kind = RTMI_XF_ROTATE_X + axis; X.x = 0.5446390509605408f; X.y = 0.838670551776886f; X.z = 0.0f;
+        F3 o, d = f3(0, 0, 0);
+        // put (x, y) into the (a, b) components of this axis: X -> (y,z), Y -> (z,x), Z -> (x,y)
+        if (axis == 0) o = f3(0.25f, x[i], y[i]); else if (axis == 1) o = f3(y[i], 0.25f, x[i]); else o = f3(x[i], y[i], 0.25f);
+        F3 n = o;
+        if (which < 2) xform_ray(&X, 0, 1, o, d); else xform_hit(&X, 0, 1, o, n);
+        if (op >= 28) o = n; // 28..39: the normal instead of the point
+        const float a = axis == 0 ? o.y : (axis == 1 ? o.z : o.x), b = axis == 0 ? o.z : (axis == 1 ? o.x : o.y);
+        r = (which & 1) ? b : a;
+        break;
+    }
     }
     out[i] = r;
+}
+// instance transforms exactly as the render kernels call them: xforms in global memory, runtime count
+__global__ void rtmi_xform_probe_kernel(const rtmi_xform *xf, int count, const float *a, const float *b, float *out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F3 o = f3(a[3 * i], a[3 * i + 1], a[3 * i + 2]), d = f3(b[3 * i], b[3 * i + 1], b[3 * i + 2]);
+    F3 p = o, nn = d;
+    const bool rot = xform_ray(xf, 0, count, o, d);
+    xform_hit(xf, 0, count, p, nn);
+    float *r = out + 13 * (size_t)i;
+    r[0] = o.x; r[1] = o.y; r[2] = o.z; r[3] = d.x; r[4] = d.y; r[5] = d.z;
+    r[6] = p.x; r[7] = p.y; r[8] = p.z; r[9] = nn.x; r[10] = nn.y; r[11] = nn.z; r[12] = rot ? 1.0f : 0.0f;
 }
 __global__ void rtmi_philox_probe_kernel(const uint32_t *ctr, const uint32_t *key, uint32_t *out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

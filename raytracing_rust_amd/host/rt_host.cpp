@@ -594,7 +594,70 @@ static void put_box(float mn[3], float mx[3], const AABB &b) {
 // BVHNode -> rtmi_bvh_node records in preorder; leaves appended left to right (so the primitive
 // index is the in-order rank the fast-cull tie rule needs).  A node over one object
 // (bvh.rs:44-45: left and right are the same Rc) stores that leaf once, referenced twice.
-int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad) {
+// Pruned ("fast-cull") traversal assumes that whatever a subtree can report lies inside the subtree's box.
+// The reference's boxes do not guarantee it: Rect::bounding_box (rect.rs:71-75) is right for the XY plane
+// only, and a MovingSphere leaves its box outside the time range it was built for.  true_bounds() is the
+// geometry's real extent (a MovingSphere over its own [time0, time1]); contained() checks every node of a
+// BVH against it.  A BVH that fails is lowered with pruning disabled (item.scale = 1e30, unbounded leaf
+// boxes): the fast kernels then visit exactly what BVHNode::hit visits.
+static bool true_bounds(const Hittable *h, AABB &out) {
+    bool dummy = false;
+    h = strip_flips(h, dummy);
+    if (auto r = dynamic_cast<const Rect *>(h)) {
+        int k, a, b;
+        plane_axes((int)r->plane_, k, a, b);
+        if (r->x0_ > r->x1_ || r->y0_ > r->y1_) return false; // never hit (rect.rs:51): no extent
+        out.min[k] = r->k_; out.max[k] = r->k_;
+        out.min[a] = r->x0_; out.max[a] = r->x1_;
+        out.min[b] = r->y0_; out.max[b] = r->y1_;
+        return true;
+    }
+    if (auto m = dynamic_cast<const MovingSphere *>(h)) {
+        const Vec3 rr(std::fabs(m->radius_), std::fabs(m->radius_), std::fabs(m->radius_));
+        const AABB b0(m->center0_ - rr, m->center0_ + rr), b1(m->center1_ - rr, m->center1_ + rr);
+        out = surrounding_box(b0, b1);
+        return true;
+    }
+    if (auto s = dynamic_cast<const Sphere *>(h)) {
+        const Vec3 rr(std::fabs(s->radius_), std::fabs(s->radius_), std::fabs(s->radius_));
+        out = AABB(s->center_ - rr, s->center_ + rr);
+        return true;
+    }
+    if (auto b = h->bounding_box(0.0, 1.0)) { out = *b; return true; } // Cube: exact
+    return false;
+}
+static bool contained(const BVHNode &n, double tol, AABB &out, bool &any) {
+    bool ok = true;
+    any = false;
+    const Hittable *ch[2] = {n.left_.get(), n.right_.get()};
+    for (int c = 0; c < 2; c++) {
+        bool dummy = false, have = false;
+        AABB tb(Vec3(0, 0, 0), Vec3(0, 0, 0));
+        const Hittable *h = strip_flips(ch[c], dummy);
+        if (auto sub = dynamic_cast<const BVHNode *>(h)) ok = contained(*sub, tol, tb, have) && ok;
+        else have = true_bounds(h, tb);
+        if (!have) continue;
+        out = any ? surrounding_box(out, tb) : tb;
+        any = true;
+    }
+    if (any)
+        for (int k = 0; k < 3; k++)
+            if (out.min[k] < n.bbox_.min[k] - tol || out.max[k] > n.bbox_.max[k] + tol) ok = false;
+    return ok;
+}
+static void moving_time_range(const Hittable *h, float &lo, float &hi) {
+    bool dummy = false;
+    h = strip_flips(h, dummy);
+    if (auto m = dynamic_cast<const MovingSphere *>(h)) {
+        lo = std::fmax(lo, (float)std::fmin(m->time0_, m->time1_));
+        hi = std::fmin(hi, (float)std::fmax(m->time0_, m->time1_));
+    } else if (auto n = dynamic_cast<const BVHNode *>(h)) {
+        moving_time_range(n->left_.get(), lo, hi);
+        moving_time_range(n->right_.get(), lo, hi);
+    }
+}
+
+int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves) {
     if (depth > out.max_bvh_depth) out.max_bvh_depth = depth;
     const int32_t id = (int32_t)out.nodes.size();
     out.nodes.push_back(rtmi_bvh_node{});
@@ -611,7 +674,7 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
         const Hittable *h = strip_flips(ch[c], flip);
         if (auto sub = dynamic_cast<const BVHNode *>(h)) {
             if (flip) throw Unsupported("FlipNormals around a BVHNode inside a BVH is not lowered");
-            child[c] = lower_bvh(*sub, depth + 1, force_moving, pad);
+            child[c] = lower_bvh(*sub, depth + 1, force_moving, pad, unbounded_leaves);
             rtmi_bvh_node &me = out.nodes[(size_t)id];
             put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, sub->bbox_);
         } else {
@@ -624,7 +687,7 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
             // the plane, rect.rs:72-73).
             const double big = 3.40282346638528859811704183484516925e+38;
             AABB lb(Vec3(-big, -big, -big), Vec3(big, big, big));
-            if (!dynamic_cast<const MovingSphere *>(h) && !dynamic_cast<const Rect *>(h)) {
+            if (!unbounded_leaves && !dynamic_cast<const MovingSphere *>(h) && !dynamic_cast<const Rect *>(h)) {
                 if (auto b = h->bounding_box(0.0, 1.0)) {
                     const Vec3 pd(pad, pad, pad);
                     lb = AABB(b->min - pd, b->max + pd);
@@ -678,8 +741,12 @@ void SceneBuilder::lower_item(const Hittable &top) {
         double scale = 0.0;
         for (int k = 0; k < 3; k++) scale = std::fmax(scale, std::fmax(std::fabs(bvh->bbox_.min[k]), std::fabs(bvh->bbox_.max[k])));
         if (!(scale < 1e30)) scale = 1e30;
-        it.scale = (float)scale;
-        it.first = lower_bvh(*bvh, 1, contains_moving(bvh), scale / 8192.0);
+        AABB tb(Vec3(0, 0, 0), Vec3(0, 0, 0));
+        bool any = false;
+        const bool prunable = contained(*bvh, scale / 65536.0, tb, any);
+        it.scale = prunable ? (float)scale : 1e30f; // 1e30: the pruning margin swallows every distance
+        it.first = lower_bvh(*bvh, 1, contains_moving(bvh), scale / 8192.0, !prunable);
+        moving_time_range(bvh, out.bvh_time_lo, out.bvh_time_hi);
     } else if (auto list = dynamic_cast<const HittableList *>(h)) {
         it.kind = RTMI_ITEM_LIST;
         it.first = (int32_t)out.prim_meta.size();
@@ -722,6 +789,7 @@ rtmi_scene_desc LoweredScene::desc() const {
     d.n_images = (uint32_t)images.size(); d.images = images.data();
     d.image_data = image_data.data(); d.image_bytes = image_data.size();
     d.max_bvh_depth = max_bvh_depth;
+    d.bvh_time_lo = bvh_time_lo; d.bvh_time_hi = bvh_time_hi;
     return d;
 }
 LoweredScene lower_scene(const Hittable &world) {

@@ -333,6 +333,9 @@ struct LoweredScene {
     std::vector<rtmi_image> images;
     std::vector<uint8_t> image_data;
     uint32_t max_bvh_depth = 0;
+    // ray times for which every MovingSphere inside a BVH stays inside the boxes built for it (its own
+    // [time0, time1]); outside, librtmi falls back from pruned to exact traversal
+    float bvh_time_lo = -3.40282346638528859811704183484516925e+38f, bvh_time_hi = 3.40282346638528859811704183484516925e+38f;
     rtmi_scene_desc desc() const;
 };
 
@@ -348,7 +351,7 @@ class SceneBuilder {
   private:
     void lower_item(const Hittable &h);
     int push_prim(const Hittable &h, bool flip, bool force_moving);
-    int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad);
+    int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves);
     std::map<const Texture *, int> tex_ids_;
     std::map<const Material *, int> mat_ids_;
 };

@@ -1,0 +1,118 @@
+"""Randomly composed test scenes (NOT reference scenes): every primitive, wrapper, material and texture of
+the hot path in arbitrary combinations the lowering supports — list items that are single primitives,
+lists or BVHs, under FlipNormals / Traslate / Rotate chains, ConstantMedium around (transformed)
+boundaries, emitters, metal with fuzz > 1, dielectrics, coincident and touching surfaces.  Built with
+the backend-agnostic `api` (C++ host mirror or oracle), so both sides construct the same world."""
+import numpy as np
+
+
+def _texture(api, rng, depth=0):
+    k = rng.integers(0, 5 if depth == 0 else 2)
+    if k == 0 or k == 1:
+        return api.SolidTexture(*rng.uniform(0.05, 0.95, 3))
+    if k == 2:
+        return api.CheckerTexture(_texture(api, rng, 1), _texture(api, rng, 1))
+    if k == 3:
+        return api.NoiseTexture(float(rng.uniform(0.05, 4.0)))
+    nx, ny = int(rng.integers(2, 17)), int(rng.integers(2, 9))
+    return api.ImageTexture(rng.integers(0, 256, (ny, nx, 3), dtype=np.uint8), nx, ny)
+
+
+def _material(api, rng):
+    k = rng.integers(0, 10)
+    if k < 4:
+        return api.Lambertian(_texture(api, rng))
+    if k < 6:
+        return api.Metal(_texture(api, rng), float(rng.choice([0.0, 0.1, 0.5, 1.0, 3.0])))
+    if k < 8:
+        return api.Dielectric(float(rng.choice([1.0, 1.3, 1.5, 2.4])))
+    return api.DiffuseLight(api.SolidTexture(*rng.uniform(0.5, 6.0, 3)))
+
+
+def _prim(api, rng, extent=3.0, allow_moving=True):
+    k = rng.integers(0, 6 if allow_moving else 5)
+    m = _material(api, rng)
+    c = rng.uniform(-extent, extent, 3)
+    if k <= 1:
+        return api.Sphere(c, float(rng.uniform(0.2, 1.2)), m)
+    if k == 2:
+        a, b = rng.uniform(-extent, extent, 2), rng.uniform(-extent, extent, 2)
+        lo, hi = np.minimum(a, b), np.maximum(a, b) + 0.3
+        plane = [api.PLANE_YZ, api.PLANE_ZX, api.PLANE_XY][int(rng.integers(0, 3))]
+        return api.Rect(plane, lo[0], lo[1], hi[0], hi[1], float(rng.uniform(-extent, extent)), m)
+    if k == 3 or k == 4:
+        a = rng.uniform(-extent, extent, 3)
+        return api.Cube(a, a + rng.uniform(0.3, 1.5, 3), m)
+    return api.MovingSphere(c, c + rng.uniform(-0.6, 0.6, 3), 0.0, 1.0, float(rng.uniform(0.2, 0.8)), m)
+
+
+def _wrap(api, rng, h, allow_flip=True):
+    for _ in range(int(rng.integers(0, 4))):
+        k = rng.integers(0, 3)
+        if k == 0:
+            h = api.Traslate(h, rng.uniform(-1.5, 1.5, 3))
+        elif k == 1:
+            axis = [api.AXIS_X, api.AXIS_Y, api.AXIS_Z][int(rng.integers(0, 3))]
+            h = api.Rotate(axis, h, float(rng.uniform(-80.0, 80.0)))
+        elif allow_flip:
+            h = api.FlipNormals(h)
+    return h
+
+
+def random_scene(api, seed, only=None):
+    """only: indices of the top-level items to keep (debugging aid; construction is identical either way)."""
+    rng = np.random.default_rng(seed)
+    api.seed_scene_rng(seed)
+    real = api.HittableList()
+
+    class _Sel:  # pushes only the selected top-level items, counts all
+        n = 0
+
+        def push(self, h):
+            if only is None or self.n in only:
+                real.push(h)
+            self.n += 1
+
+    world = _Sel()
+    # something to stand on and something to see by, so that paths are long and carry radiance
+    world.push(api.Rect(api.PLANE_ZX, -6.0, -6.0, 6.0, 6.0, -3.2, api.Lambertian(_texture(api, rng))))
+    world.push(api.Sphere((0.0, 7.0, 0.0), 2.5, api.DiffuseLight(api.SolidTexture(4.0, 4.0, 4.0))))
+    for _ in range(int(rng.integers(3, 9))):
+        k = rng.integers(0, 10)
+        if k < 4:  # a single primitive, possibly wrapped
+            world.push(_wrap(api, rng, _prim(api, rng)))
+        elif k < 5:  # a nested list
+            inner = api.HittableList()
+            for _ in range(int(rng.integers(2, 5))):
+                p = _prim(api, rng)
+                inner.push(api.FlipNormals(p) if rng.random() < 0.2 else p)
+            world.push(_wrap(api, rng, inner))
+        elif k < 8:  # a BVH (moving spheres make every static sphere in it a moving one on the device)
+            n = int(rng.integers(1, 40))
+            moving = rng.random() < 0.4
+            objs = []
+            for _ in range(n):
+                p = _prim(api, rng, extent=2.5, allow_moving=moving)
+                objs.append(api.FlipNormals(p) if rng.random() < 0.1 else p)
+            world.push(_wrap(api, rng, api.BVHNode(objs, 0.0, 1.0)))
+        else:  # a participating medium inside a (transformed) boundary; FlipNormals outside only
+            b = api.Sphere(rng.uniform(-2, 2, 3), float(rng.uniform(0.8, 2.0)), api.Dielectric(1.5)) if rng.random() < 0.5 \
+                else api.Cube(rng.uniform(-2.5, 0, 3), rng.uniform(0.5, 2.5, 3), api.Dielectric(1.5))
+            b = _wrap(api, rng, b, allow_flip=False)
+            med = api.ConstantMedium(b, float(rng.choice([0.01, 0.2, 1.0, 5.0])), _texture(api, rng))
+            world.push(api.FlipNormals(med) if rng.random() < 0.1 else med)
+    return real
+
+
+def random_camera(api, seed, nx, ny):
+    rng = np.random.default_rng(seed + 10_000)
+    d = rng.normal(size=3)
+    d[1] = abs(d[1]) * 0.5
+    look_from = d / np.linalg.norm(d) * rng.uniform(7.0, 12.0)
+    aperture = float(rng.choice([0.0, 0.0, 0.2]))
+    return api.Camera(look_from, rng.uniform(-0.5, 0.5, 3), (0.0, 1.0, 0.0), float(rng.uniform(35.0, 70.0)), nx / ny,
+                      aperture, float(np.linalg.norm(look_from)), 0.0, 1.0)
+
+
+def build(api, seed, nx, ny, only=None):
+    return random_camera(api, seed, nx, ny), random_scene(api, seed, only)

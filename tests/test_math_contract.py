@@ -82,3 +82,66 @@ def test_device_philox_kat():
     out = np.zeros((len(KAT), 4), np.uint32)
     assert lib.rtmi_probe_philox(ctr.ctypes.data, key.ctypes.data, out.ctypes.data, len(KAT)) == 0
     assert out.tolist() == [k[2] for k in KAT]
+
+
+@pytest.mark.gpu
+def test_instance_transforms_on_device():
+    """Traslate / Rotate{X,Y,Z} chains as the render kernels apply them (traslate.rs:18-24, rotate.rs:85-113),
+    against the same fp32 operations in numpy: world->object for the ray, object->world for the hit record."""
+    import ctypes as C
+
+    from raytracing_rust_amd import abi
+
+    lib = abi.load_rtmi()
+    rng = np.random.default_rng(3)
+    n = 4096
+    a = (rng.normal(size=(n, 3)) * 4).astype(np.float32)
+    b = rng.normal(size=(n, 3)).astype(np.float32)
+    AB = {1: (1, 2), 2: (2, 0), 3: (0, 1)}  # Axis::X/Y/Z -> (a_axis, b_axis), rotate.rs:13-19
+
+    def fwd(o, xf):  # Rotate::hit ray part / Traslate::hit
+        o = o.copy()
+        if xf.kind == 0:
+            return o - np.array([xf.x, xf.y, xf.z], np.float32)
+        ia, ib = AB[xf.kind]
+        s, c = np.float32(xf.x), np.float32(xf.y)
+        na = c * o[:, ia] + s * o[:, ib]
+        nb = (-s) * o[:, ia] + c * o[:, ib]
+        o[:, ia], o[:, ib] = na, nb
+        return o
+
+    def inv(p, xf, is_point):
+        p = p.copy()
+        if xf.kind == 0:
+            return p + np.array([xf.x, xf.y, xf.z], np.float32) if is_point else p
+        ia, ib = AB[xf.kind]
+        s, c = np.float32(xf.x), np.float32(xf.y)
+        na = c * p[:, ia] - s * p[:, ib]
+        nb = s * p[:, ia] + c * p[:, ib]
+        p[:, ia], p[:, ib] = na, nb
+        return p
+
+    chains = [[(1, 33.0)], [(2, 33.0)], [(3, 33.0)], [(3, 180.0)], [(0, (0.5, -1.0, 2.0))],
+              [(0, (0.5, -1.0, 2.0)), (3, -40.0), (2, 20.0)], [(3, 10.0), (1, -70.0), (0, (1.0, 1.0, 1.0)), (3, 5.0)]]
+    for chain in chains:
+        xs = (abi.Xform * len(chain))()
+        for k, (kind, arg) in enumerate(chain):
+            xs[k].kind = kind
+            if kind == 0:
+                xs[k].x, xs[k].y, xs[k].z = arg
+            else:
+                xs[k].x, xs[k].y, xs[k].z = np.sin(np.radians(arg)), np.cos(np.radians(arg)), 0.0
+        out = np.zeros((n, 13), np.float32)
+        assert lib.rtmi_probe_xform(xs, len(chain), a.ctypes.data, b.ctypes.data, out.ctypes.data, n) == 0
+        o, d, p, nn = a, b, a, b
+        for xf in xs:  # outermost wrapper first
+            o = fwd(o, xf)
+            d = fwd(d, xf) if xf.kind != 0 else d
+        for xf in reversed(list(xs)):  # innermost first on the way back
+            p = inv(p, xf, True)
+            nn = inv(nn, xf, False)
+        assert np.array_equal(out[:, 0:3], o), chain
+        assert np.array_equal(out[:, 3:6], d), chain
+        assert np.array_equal(out[:, 6:9], p), chain
+        assert np.array_equal(out[:, 9:12], nn), chain
+        assert (out[:, 12] == (1.0 if any(k for k, _ in chain) else 0.0)).all()

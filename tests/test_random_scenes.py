@@ -1,0 +1,97 @@
+"""Randomly composed scenes (tests/scenes_random.py): every primitive / wrapper / material / texture
+combination the lowering supports.  CPU: the C++ mirror's f64 evaluation equals the f64 oracle
+bitwise and every scene lowers.  GPU: the device equals the fp32 oracle bit-for-bit (radiance,
+quantised pixels and path signatures) for every kernel variant."""
+import numpy as np
+import pytest
+
+import scenes_random
+from oracle.oracle import ARITH_DEVICE, SKY, THROUGHPUT_FORM
+from raytracing_rust_amd import abi
+
+SEEDS = list(range(1, 25))
+TOL = 1e-4  # north star: per-channel linear radiance
+
+
+@pytest.mark.parametrize("seed", SEEDS[:12])
+def test_mirror_equals_f64_oracle_and_lowers(host, orc64, seed):
+    nx, ny = 16, 12
+    cam, world = scenes_random.build(host, seed, nx, ny)
+    camo, worldo = scenes_random.build(orc64, seed, nx, ny)
+    row = 5
+    ref = orc64.render(camo, worldo, nx, ny, 1, seed=42, rows=(row, row + 1))
+    for i in range(nx):
+        c = host.color_sample(cam, world, nx, ny, i, ny - 1 - row, 0, seed=42)
+        assert np.array_equal(c, ref["mean"][row, i]), (seed, i)
+    a = host.lower(world).arrays()
+    assert len(a["items"]) >= 5 and a["max_bvh_depth"] <= abi.RTMI_MAX_BVH_DEPTH
+    orc64.free_all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_device_equals_fp32_oracle_on_random_scenes(host, orc32, seed):
+    nx, ny, ns = 40, 24, 6
+    cam, world = scenes_random.build(host, seed, nx, ny)
+    sc = host.lower(world)
+    camo, worldo = scenes_random.build(orc32, seed, nx, ny)
+    sky = SKY if seed % 3 == 0 else 0
+    ref = orc32.render(camo, worldo, nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM | sky)
+    dsky = abi.RTMI_FLAG_SKY if sky else 0
+    for label, flags in (("exact", 0), ("coop-fast", abi.RTMI_FLAG_FAST_CULL),
+                         ("perlane-fast", abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL),
+                         ("async-fast", abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL)):
+        got = sc.render(cam, nx, ny, ns, seed=42, flags=flags | dsky, sig=True)
+        diff = np.abs(got["linear"].astype(np.float64) - ref["linear"].astype(np.float64))
+        finite = np.isfinite(ref["linear"])
+        assert int((diff[finite] > TOL).sum()) == 0, (seed, label, float(diff[finite].max()))
+        assert np.array_equal(got["linear"], ref["linear"], equal_nan=True), (seed, label)
+        assert np.array_equal(got["rgb8"].astype(np.int32), ref["rgb"]), (seed, label)
+        assert np.array_equal(got["sig"], ref["sig"]), (seed, label)
+    print(seed, "mean radiance", float(np.nanmean(ref["linear"])), "items", len(sc.arrays()["items"]))
+    orc32.free_all()
+
+
+def _bvh_world(api, with_zx_rect, sphere_times=(0.0, 1.0)):
+    lamb = api.Lambertian(api.SolidTexture(0.5, 0.5, 0.5))
+    objs = [api.Sphere((x, 0.0, z), 0.4, lamb) for x in (-2.0, 0.0, 2.0) for z in (-2.0, 0.0, 2.0)]
+    objs.append(api.MovingSphere((0.0, 1.5, 0.0), (0.5, 1.8, 0.0), sphere_times[0], sphere_times[1], 0.4, lamb))
+    if with_zx_rect:
+        objs.append(api.Rect(api.PLANE_ZX, -3.0, -3.0, 3.0, 3.0, -0.6, lamb))  # its reference bbox is the XY one
+    w = api.HittableList()
+    w.push(api.Sphere((0.0, 8.0, 0.0), 3.0, api.DiffuseLight(api.SolidTexture(4.0, 4.0, 4.0))))
+    w.push(api.BVHNode(objs, 0.0, 1.0))
+    return w
+
+
+def test_lowering_disables_pruning_when_boxes_do_not_contain_their_primitives(host):
+    """Rect::bounding_box (rect.rs:71-75) is the XY-plane box whatever the plane: a BVH holding a ZX rect has
+    boxes that do not contain it, so the lowering turns pruning off for that BVH (scale = 1e30)."""
+    host.seed_scene_rng(1)
+    a = host.lower(_bvh_world(host, False)).arrays()
+    b = host.lower(_bvh_world(host, True)).arrays()
+    assert a["items"][1].kind == abi.ITEM_BVH and a["items"][1].scale < 100.0
+    assert b["items"][1].kind == abi.ITEM_BVH and b["items"][1].scale == np.float32(1e30)
+    d = host.lower(_bvh_world(host, False, sphere_times=(0.25, 0.75))).desc()
+    assert (d.bvh_time_lo, d.bvh_time_hi) == (0.25, 0.75)
+    d0 = host.lower(_bvh_world(host, False)).desc()
+    assert (d0.bvh_time_lo, d0.bvh_time_hi) == (0.0, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["zx_rect_in_bvh", "shutter_beyond_sphere_times"])
+def test_pruned_equals_exact_when_boxes_are_not_trustworthy(host, orc32, case):
+    nx, ny, ns = 48, 32, 8
+    times = (0.25, 0.75) if case == "shutter_beyond_sphere_times" else (0.0, 1.0)
+    worlds, cams = [], []
+    for api in (host, orc32):
+        api.seed_scene_rng(1)
+        worlds.append(_bvh_world(api, case == "zx_rect_in_bvh", times))
+        cams.append(api.Camera((5.0, 4.0, 7.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 45.0, nx / ny, 0.0, 10.0, 0.0, 1.0))
+    sc = host.lower(worlds[0])
+    ref = orc32.render(cams[1], worlds[1], nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM)
+    for flags in (0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL):
+        got = sc.render(cams[0], nx, ny, ns, seed=42, flags=flags, sig=True)
+        assert np.array_equal(got["sig"], ref["sig"]), (case, flags)
+        assert np.array_equal(got["linear"], ref["linear"]), (case, flags)
+    orc32.free_all()
