@@ -2,6 +2,8 @@
 combination the lowering supports.  CPU: the C++ mirror's f64 evaluation equals the f64 oracle
 bitwise and every scene lowers.  GPU: the device equals the fp32 oracle bit-for-bit (radiance,
 quantised pixels and path signatures) for every kernel variant."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,9 @@ from oracle.oracle import ARITH_DEVICE, SKY, THROUGHPUT_FORM
 from raytracing_rust_amd import abi
 
 SEEDS = list(range(1, 25))
+if os.environ.get("RTMI_RANDOM_SEEDS"):  # e.g. "25-200": an ad-hoc wider sweep
+    _lo, _hi = os.environ["RTMI_RANDOM_SEEDS"].split("-")
+    SEEDS = list(range(int(_lo), int(_hi) + 1))
 TOL = 1e-4  # north star: per-channel linear radiance
 
 
