@@ -1,13 +1,25 @@
 #!/usr/bin/env python3
-"""Recover the hit distance of every bounce of one (pixel, sample) from path signatures, device vs fp32 oracle."""
-import os, sys
+"""Per-bounce hit distances of individual camera samples, recovered from path signatures (GPU box).
+
+usage: python tools/diag_trace.py <random-scene seed> [device flags=0]
+
+The path signature of a pixel is the wrapping sum of mix(bits(t), bounce) over every hit of every sample;
+mix is invertible, so rendering with ns = s, s+1 and max_depth = k-1, k isolates the hit distance of sample s
+at bounce k.  Prints them for the first mismatching pixels, device (with `flags`) next to the fp32 oracle:
+shows at which bounce two implementations part and whether by rounding or by a different hit."""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
-from oracle.oracle import Oracle, ARITH_DEVICE, THROUGHPUT_FORM
-from raytracing_rust_amd import Host, abi
-nx, ny, NS = 40, 24, 6
-host = Host(); orc = Oracle("f32")
-M32 = 0xffffffff
+import scenes_random
+from oracle.oracle import ARITH_DEVICE, THROUGHPUT_FORM, Oracle
+from raytracing_rust_amd import Host
+
+M32 = 0xFFFFFFFF
+
+
 def unmix(h, k):
     x = h & M32
     x ^= x >> 16
@@ -16,43 +28,42 @@ def unmix(h, k):
     x = (x * pow(0x7FEB352D, -1, 1 << 32)) & M32
     x ^= x >> 16
     x ^= ((k + 1) * 0x9E3779B9) & M32
-    return np.array([x], np.uint32).view(np.float32)[0]
-def cam(api):
-    return api.Camera((6.0, 3.0, 7.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 45.0, nx / ny, 0.0, 10.0, 0.0, 1.0)
-lamb = lambda a: a.Lambertian(a.SolidTexture(0.6, 0.5, 0.4))
-def build(a):
-    w = a.HittableList()
-    w.push(a.Sphere((0.0, 9.0, 0.0), 3.0, a.DiffuseLight(a.SolidTexture(4.0, 4.0, 4.0))))
-    w.push(a.Rotate(getattr(a, sys.argv[1] if len(sys.argv) > 1 else "AXIS_Z"), a.Sphere((0.5, 0.2, -0.3), 1.5, lamb(a)), 33.0))
-    return w
-host.seed_scene_rng(1); orc.seed_scene_rng(1)
-ch, wh = cam(host), build(host); co, wo = cam(orc), build(orc)
-sc = host.lower(wh)
-FLAGS = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-def sig_dev(ns, md): return sc.render(ch, nx, ny, ns, seed=42, flags=FLAGS, sig=True, max_depth=md)["sig"]
-def sig_orc(ns, md): return orc.render(co, wo, nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM, max_depth=md)["sig"]
-full_d, full_o = sig_dev(NS, 50), sig_orc(NS, 50)
-bad = np.argwhere(full_d != full_o)
-print("mismatching pixels", len(bad), bad[:5].tolist())
-def contrib(fn, r, c, s, k):
-    def one(ns, md): return int(fn(ns, md)[r, c]) if ns > 0 and md >= 0 else 0
-    hi = one(s + 1, k) - one(s, k)
-    lo = (one(s + 1, k - 1) - one(s, k - 1)) if k > 0 else 0
-    return (hi - lo) % (1 << 64)
-cache = {}
-def cached(fn):
-    def g(ns, md):
-        key = (fn.__name__, ns, md)
-        if key not in cache: cache[key] = fn(ns, md)
+    return float(np.array([x], np.uint32).view(np.float32)[0])
+
+
+def main():
+    seed = int(sys.argv[1])
+    flags = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    nx, ny, ns = 40, 24, 6
+    host, orc = Host(), Oracle("f32")
+    cam, world = scenes_random.build(host, seed, nx, ny)
+    camo, worldo = scenes_random.build(orc, seed, nx, ny)
+    sc = host.lower(world)
+    cache = {}
+
+    def sig(which, n, md):
+        if n <= 0 or md < 0:
+            return np.zeros((ny, nx), np.uint64)
+        key = (which, n, md)
+        if key not in cache:
+            cache[key] = (sc.render(cam, nx, ny, n, seed=42, flags=flags, sig=True, max_depth=md)["sig"] if which == "dev"
+                          else orc.render(camo, worldo, nx, ny, n, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM, max_depth=md)["sig"])
         return cache[key]
-    g.__name__ = fn.__name__
-    return g
-sd, so = cached(sig_dev), cached(sig_orc)
-for (r, c) in bad[:4]:
-    for s in range(NS):
-        line = []
-        for k in range(3):
-            cd, co_ = contrib(sd, r, c, s, k), contrib(so, r, c, s, k)
-            td = unmix(cd, k) if cd else None; to = unmix(co_, k) if co_ else None
-            line.append("k%d dev %s orc %s%s" % (k, None if td is None else "%.6f" % td, None if to is None else "%.6f" % to, "" if cd == co_ else " <<<"))
-        print("px", r, c, "s", s, " | ".join(line))
+
+    def contrib(which, r, c, s, k):
+        one = lambda n, md: int(sig(which, n, md)[r, c])
+        return ((one(s + 1, k) - one(s, k)) - (one(s + 1, k - 1) - one(s, k - 1))) % (1 << 64)
+
+    bad = np.argwhere(sig("dev", ns, 50) != sig("orc", ns, 50))
+    print("seed", seed, "flags", flags, "mismatching pixels", len(bad), bad[:6].tolist())
+    for (r, c) in bad[:3]:
+        for s in range(ns):
+            parts = []
+            for k in range(6):
+                a, b = contrib("dev", r, c, s, k), contrib("orc", r, c, s, k)
+                parts.append("k%d %s|%s%s" % (k, "-" if not a else "%.6g" % unmix(a, k), "-" if not b else "%.6g" % unmix(b, k), "" if a == b else " <<<"))
+            print(" px", r, c, "sample", s, "  ".join(parts))
+
+
+if __name__ == "__main__":
+    main()
