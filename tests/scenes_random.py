@@ -25,7 +25,7 @@ def _material(api, rng):
     if k < 6:
         return api.Metal(_texture(api, rng), float(rng.choice([0.0, 0.1, 0.5, 1.0, 3.0])))
     if k < 8:
-        return api.Dielectric(float(rng.choice([1.0, 1.3, 1.5, 2.4])))
+        return api.Dielectric(float(rng.choice([1.0, 1.3, 1.5, 2.4, 0.7])))
     return api.DiffuseLight(api.SolidTexture(*rng.uniform(0.5, 6.0, 3)))
 
 
@@ -34,10 +34,13 @@ def _prim(api, rng, extent=3.0, allow_moving=True):
     m = _material(api, rng)
     c = rng.uniform(-extent, extent, 3)
     if k <= 1:
-        return api.Sphere(c, float(rng.uniform(0.2, 1.2)), m)
+        r = float(rng.uniform(0.2, 1.2))
+        return api.Sphere(c, -r if rng.random() < 0.1 else r, m)  # negative radius: inward normals (hollow glass)
     if k == 2:
         a, b = rng.uniform(-extent, extent, 2), rng.uniform(-extent, extent, 2)
         lo, hi = np.minimum(a, b), np.maximum(a, b) + 0.3
+        if rng.random() < 0.05:
+            lo, hi = hi, lo  # inverted extents: can never be hit (like the reference's final_scene light)
         plane = [api.PLANE_YZ, api.PLANE_ZX, api.PLANE_XY][int(rng.integers(0, 3))]
         return api.Rect(plane, lo[0], lo[1], hi[0], hi[1], float(rng.uniform(-extent, extent)), m)
     if k == 3 or k == 4:
@@ -94,12 +97,15 @@ def random_scene(api, seed, only=None):
             for _ in range(n):
                 p = _prim(api, rng, extent=2.5, allow_moving=moving)
                 objs.append(api.FlipNormals(p) if rng.random() < 0.1 else p)
+            if n > 6 and rng.random() < 0.3:  # a BVH built earlier as one of the objects of this one
+                inner = api.BVHNode(objs[:n // 2], 0.0, 1.0)
+                objs = [inner] + objs[n // 2:]
             world.push(_wrap(api, rng, api.BVHNode(objs, 0.0, 1.0)))
         else:  # a participating medium inside a (transformed) boundary; FlipNormals outside only
             b = api.Sphere(rng.uniform(-2, 2, 3), float(rng.uniform(0.8, 2.0)), api.Dielectric(1.5)) if rng.random() < 0.5 \
                 else api.Cube(rng.uniform(-2.5, 0, 3), rng.uniform(0.5, 2.5, 3), api.Dielectric(1.5))
             b = _wrap(api, rng, b, allow_flip=False)
-            med = api.ConstantMedium(b, float(rng.choice([0.01, 0.2, 1.0, 5.0])), _texture(api, rng))
+            med = api.ConstantMedium(b, float(rng.choice([0.0, 0.01, 0.2, 1.0, 5.0])), _texture(api, rng))
             world.push(api.FlipNormals(med) if rng.random() < 0.1 else med)
     return real
 
