@@ -1,0 +1,227 @@
+//! Raw FFI of include/rtmi.h (ABI version 2): one declaration per entry point, one `#[repr(C)]` struct per
+//! C struct, same field order.  UNVERIFIED SOURCE: the build image has no Rust toolchain; the layouts are
+//! kept in sync with the tested ctypes binding (raytracing_rust_amd/abi.py) by tests/test_rust_binding_source.py.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const RTMI_ABI_VERSION: u32 = 2;
+pub const RTMI_FLAG_FAST_CULL: u32 = 1;
+pub const RTMI_FLAG_PATH_SIG: u32 = 2;
+pub const RTMI_FLAG_PROFILE: u32 = 4;
+pub const RTMI_FLAG_SYNC: u32 = 8;
+pub const RTMI_FLAG_ASYNC: u32 = 16;
+pub const RTMI_FLAG_SKY: u32 = 32;
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiTexture {
+    pub kind: i32,
+    pub i0: i32,
+    pub i1: i32,
+    pub pad: i32,
+    pub f0: f32,
+    pub f1: f32,
+    pub f2: f32,
+    pub f3: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiPerlin {
+    pub ranvec: [f32; 1024],
+    pub perm: [i32; 768],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiImage {
+    pub offset: u64,
+    pub nx: u32,
+    pub ny: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiMaterial {
+    pub kind: i32,
+    pub tex: i32,
+    pub param: f32,
+    pub flags: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiPrimMeta {
+    pub material: i32,
+    pub flags: u32,
+    pub inv_dt: f32,
+    pub r#type: i32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiBvhNode {
+    pub lmin: [f32; 3],
+    pub lmax: [f32; 3],
+    pub rmin: [f32; 3],
+    pub rmax: [f32; 3],
+    pub left: i32,
+    pub right: i32,
+    pub pad: [i32; 2],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiXform {
+    pub kind: i32,
+    pub x: f32,
+    pub y: f32,
+    pub z: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiItem {
+    pub kind: i32,
+    pub first: i32,
+    pub count: i32,
+    pub flags: u32,
+    pub xform_first: i32,
+    pub xform_count: i32,
+    pub medium_material: i32,
+    pub neg_inv_density: f32,
+    pub root_min: [f32; 3],
+    pub root_max: [f32; 3],
+    pub scale: f32,
+    pub pad: i32,
+}
+
+#[repr(C)]
+pub struct RtmiSceneDesc {
+    pub abi_version: u32,
+    pub n_items: u32,
+    pub items: *const RtmiItem,
+    pub n_prims: u32,
+    pub prim_a: *const f32,
+    pub prim_b: *const f32,
+    pub prim_meta: *const RtmiPrimMeta,
+    pub n_nodes: u32,
+    pub nodes: *const RtmiBvhNode,
+    pub n_xforms: u32,
+    pub xforms: *const RtmiXform,
+    pub n_materials: u32,
+    pub materials: *const RtmiMaterial,
+    pub n_textures: u32,
+    pub textures: *const RtmiTexture,
+    pub n_perlin: u32,
+    pub perlin: *const RtmiPerlin,
+    pub n_images: u32,
+    pub images: *const RtmiImage,
+    pub image_data: *const u8,
+    pub image_bytes: u64,
+    pub max_bvh_depth: u32,
+    pub bvh_time_lo: f32,
+    pub bvh_time_hi: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiCamera {
+    pub origin: [f32; 3],
+    pub lower_left_corner: [f32; 3],
+    pub horizontal: [f32; 3],
+    pub vertical: [f32; 3],
+    pub u: [f32; 3],
+    pub v: [f32; 3],
+    pub time0: f32,
+    pub time1: f32,
+    pub lens_radius: f32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiRenderParams {
+    pub nx: u32,
+    pub ny: u32,
+    pub ns: u32,
+    pub max_depth: u32,
+    pub t_min: f32,
+    pub flags: u32,
+    pub seed: u64,
+    pub tile_rank: u32,
+    pub tile_world: u32,
+    pub spp_chunks: u32,
+    pub shade_threshold: u32,
+    pub path_sig: u64,
+    pub prof: u64,
+    pub sample_buffer_bytes: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct RtmiTexel {
+    pub r: f32,
+    pub g: f32,
+    pub b: f32,
+    pub rgb8: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct RtmiStats {
+    pub kernel_ms: f64,
+    pub render_ms: f64,
+    pub samples: u64,
+    pub tiles: u32,
+    pub chunks: u32,
+    pub blocks: u32,
+    pub reserved: u32,
+}
+
+#[repr(C)]
+pub struct RtmiScene {
+    _private: [u8; 0],
+}
+
+extern "C" {
+    pub fn rtmi_device_count() -> c_int;
+    pub fn rtmi_last_error() -> *const c_char;
+    pub fn rtmi_scene_create(desc: *const RtmiSceneDesc, device: c_int, out: *mut *mut RtmiScene) -> c_int;
+    pub fn rtmi_scene_destroy(scene: *mut RtmiScene);
+    pub fn rtmi_local_tiles(p: *const RtmiRenderParams) -> u32;
+    pub fn rtmi_render_prepare(scene: *mut RtmiScene, p: *const RtmiRenderParams) -> c_int;
+    pub fn rtmi_render_device(
+        scene: *mut RtmiScene,
+        cam: *const RtmiCamera,
+        p: *const RtmiRenderParams,
+        d_texels: *mut c_void,
+        stream: *mut c_void,
+        stats: *mut RtmiStats,
+    ) -> c_int;
+    pub fn rtmi_render(
+        scene: *mut RtmiScene,
+        cam: *const RtmiCamera,
+        p: *const RtmiRenderParams,
+        out_linear_rgb: *mut f32,
+        out_rgb8: *mut u8,
+        out_path_sig: *mut u64,
+        stats: *mut RtmiStats,
+    ) -> c_int;
+    pub fn rtmi_untile(
+        p: *const RtmiRenderParams,
+        gathered: *const RtmiTexel,
+        out_linear_rgb: *mut f32,
+        out_rgb8: *mut u8,
+    ) -> c_int;
+    pub fn rtmi_ppm_p3(nx: u32, ny: u32, rgb8: *const u8, buf: *mut c_char, cap: usize) -> usize;
+    pub fn rtmi_probe_math(op: c_int, x: *const f32, y: *const f32, out: *mut f32, n: u32) -> c_int;
+    pub fn rtmi_probe_philox(ctr: *const u32, key: *const u32, out: *mut u32, n: u32) -> c_int;
+    pub fn rtmi_probe_xform(
+        xforms: *const RtmiXform,
+        count: u32,
+        a: *const f32,
+        b: *const f32,
+        out: *mut f32,
+        n: u32,
+    ) -> c_int;
+}
