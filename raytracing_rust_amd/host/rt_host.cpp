@@ -757,10 +757,31 @@ void SceneBuilder::lower_item(const Hittable &top) {
             it.count++;
         }
     } else {
+        // A run of consecutive plain primitives of the world list (no transform, no medium) becomes ONE list
+        // item: the device scans its primitives in order with the shrinking t_max exactly as it scans items
+        // (hittable.rs:37-47), without the per-item overhead.  FlipNormals goes to the primitive's flag.
+        if (!medium && it.xform_count == 0) {
+            if (run_item_ >= 0) {
+                rtmi_item &run = out.items[(size_t)run_item_];
+                if (run.first + run.count == (int32_t)out.prim_meta.size()) {
+                    push_prim(*h, flip, false);
+                    run.count++;
+                    return;
+                }
+            }
+            it.kind = RTMI_ITEM_LIST;
+            it.flags = 0u;
+            it.first = push_prim(*h, flip, false);
+            it.count = 1;
+            out.items.push_back(it);
+            run_item_ = (int)out.items.size() - 1;
+            return;
+        }
         it.kind = RTMI_ITEM_LIST;
         it.first = push_prim(*h, false, false);
         it.count = 1;
     }
+    run_item_ = -1;
     out.items.push_back(it);
 }
 

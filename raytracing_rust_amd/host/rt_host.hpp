@@ -352,6 +352,7 @@ class SceneBuilder {
     void lower_item(const Hittable &h);
     int push_prim(const Hittable &h, bool flip, bool force_moving);
     int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves);
+    int run_item_ = -1; // index of the item that collects the current run of plain top-level primitives
     std::map<const Texture *, int> tex_ids_;
     std::map<const Material *, int> mat_ids_;
 };

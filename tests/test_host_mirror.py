@@ -42,14 +42,17 @@ def test_lowering_final_scene(host):
     _, world = scenes.build(host, "final_scene", 8, 8, seed=1)
     a = host.lower(world).arrays()
     items = a["items"]
-    assert len(items) == 11
-    assert [it.kind for it in items] == [abi.ITEM_BVH] + [abi.ITEM_LIST] * 9 + [abi.ITEM_BVH]
-    assert [bool(it.flags & abi.ITEMFLAG_MEDIUM) for it in items] == [False] * 6 + [True, True] + [False] * 3
-    assert items[10].xform_count == 2 and items[0].xform_count == 0
+    # tests/test.rs:426-522 pushes 11 objects; runs of plain primitives (the light rect + 4 spheres, then the
+    # earth + Perlin spheres) are lowered as one list item each
+    assert len(items) == 6
+    assert [it.kind for it in items] == [abi.ITEM_BVH, abi.ITEM_LIST, abi.ITEM_LIST, abi.ITEM_LIST, abi.ITEM_LIST, abi.ITEM_BVH]
+    assert [it.count for it in items[1:5]] == [5, 1, 1, 2]
+    assert [bool(it.flags & abi.ITEMFLAG_MEDIUM) for it in items] == [False, False, True, True, False, False]
+    assert items[5].xform_count == 2 and items[0].xform_count == 0
     xf = a["xforms"]
     assert xf[0].kind == abi.XF_TRANSLATE and (xf[0].x, xf[0].y, xf[0].z) == (-100.0, 270.0, 395.0)
     assert xf[1].kind == abi.XF_ROTATE_Y and xf[1].x == pytest.approx(np.sin(np.radians(15.0)), rel=1e-7)
-    assert items[7].neg_inv_density == np.float32(-1.0) / np.float32(0.0001)
+    assert items[3].neg_inv_density == np.float32(-1.0) / np.float32(0.0001)
     types = [m.type for m in a["prim_meta"]]
     assert types.count(abi.PRIM_CUBE) == 400
     assert 0 < a["max_bvh_depth"] <= abi.RTMI_MAX_BVH_DEPTH
@@ -65,10 +68,13 @@ def test_lowering_final_scene(host):
 def test_lowering_cornell_flips_and_order(host):
     _, world = scenes.build(host, "cornell_box", 8, 8)
     a = host.lower(world).arrays()
-    assert [it.flags & abi.ITEMFLAG_FLIP for it in a["items"]] == [1, 0, 0, 1, 0, 1, 0, 0]
+    # the six walls (tests/test.rs:249-300: three of them inside FlipNormals) are one run of plain primitives:
+    # one list item, the flips travel as primitive flags; then the two transformed boxes
+    assert [(it.kind, it.count, it.flags & abi.ITEMFLAG_FLIP) for it in a["items"]] == [(abi.ITEM_LIST, 6, 0), (abi.ITEM_LIST, 1, 0), (abi.ITEM_LIST, 1, 0)]
+    assert [m.flags & 1 for m in a["prim_meta"]] == [1, 0, 0, 1, 0, 1, 0, 0]
     assert [m.type for m in a["prim_meta"]] == [abi.PRIM_RECT] * 6 + [abi.PRIM_CUBE] * 2
     assert [(m.flags >> 8) & 3 for m in a["prim_meta"]][:6] == [0, 0, 1, 1, 1, 2]  # YZ YZ ZX ZX ZX XY
-    assert a["items"][6].xform_count == 2 and a["xforms"][0].kind == abi.XF_TRANSLATE
+    assert a["items"][1].xform_count == 2 and a["xforms"][0].kind == abi.XF_TRANSLATE
 
 
 def test_random_spheres_static_spheres_share_the_moving_code_path(host):
