@@ -47,7 +47,10 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
                                                bool &have, float &t_out, int &pf_out, bool &overflow,
                                                unsigned long long *prof, int slot) {
     const int lane = threadIdx.x & 63;
-    volatile uint32_t *pool = wlds;
+    // Plain (non-volatile) LDS accesses: every exchange between lanes is separated by a wavefront-scope
+    // fence + wave barrier, and plain accesses let the compiler keep the LDS address space (ds_read/write_b64;
+    // volatile ones became flat loads/stores with a full wait each — five per iteration).
+    uint2 *pool = reinterpret_cast<uint2 *>(wlds);
     float4 *ctx = reinterpret_cast<float4 *>(wlds + 2 * cap);
     unsigned long long *best = reinterpret_cast<unsigned long long *>(wlds + 2 * cap + 64 * 12);
 
@@ -63,8 +66,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
         ctx[lane * 3 + 1] = make_float4(R.d.x, R.d.y, R.d.z, q_min);
         ctx[lane * 3 + 2] = make_float4(R.inv_d.x, R.inv_d.y, R.inv_d.z, q_max);
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u));
-        pool[2 * pos] = ((uint32_t)lane << 26) | (uint32_t)root;
-        pool[2 * pos + 1] = __float_as_uint(q_min); // entry distance of the root: conservative
+        pool[pos] = make_uint2(((uint32_t)lane << 26) | (uint32_t)root, __float_as_uint(q_min)); // root entry distance: conservative
     }
     int top = __popcll(m_act);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -89,10 +91,10 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
             const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
             if (r < take) {
                 const int idx = top - 1 - r;
-                const uint32_t e0 = pool[2 * idx];
-                tent = __uint_as_float(pool[2 * idx + 1]);
-                cur = e0 & 0x03ffffffu;
-                ray = (int)(e0 >> 26);
+                const uint2 e = pool[idx];
+                tent = __uint_as_float(e.y);
+                cur = e.x & 0x03ffffffu;
+                ray = (int)(e.x >> 26);
             }
         }
         top -= take;
@@ -112,7 +114,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
                 cray = ray;
             }
             // the ray's best hit so far -> pruning limit
-            const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(&best[ray]);
+            const unsigned long long key = best[ray];
             float limit = RTMI_FLT_MAX;
             if (key != COOP_SENTINEL) {
                 const float bt = sort2f((uint32_t)(key >> 32));
@@ -155,8 +157,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
         const unsigned long long m_push = __ballot(push);
         if (push) {
             const int pos = top + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_push >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
-            pool[2 * pos] = ((uint32_t)ray << 26) | push_ref;
-            pool[2 * pos + 1] = __float_as_uint(push_t);
+            pool[pos] = make_uint2(((uint32_t)ray << 26) | push_ref, __float_as_uint(push_t));
         }
         top += __popcll(m_push);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -165,7 +166,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (active) {
-        const unsigned long long key = *reinterpret_cast<volatile unsigned long long *>(&best[lane]);
+        const unsigned long long key = best[lane];
         if (key != COOP_SENTINEL) {
             have = true;
             t_out = sort2f((uint32_t)(key >> 32));
