@@ -60,8 +60,8 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
     // ---- publish ray contexts, push roots
     best[lane] = COOP_SENTINEL;
     if (active) {
-        // 48 B per ray; a, inv_a and the pruning margin are recomputed by the worker with the same
-        // operations on the same values (bit-identical), which keeps the wave's LDS under 10 KB
+        // 48 B per ray keeps the wave's LDS under 10 KB; a and inv_a are recomputed by a worker when it
+        // first tests a sphere of this ray (same operations on the same values: bit-identical)
         ctx[lane * 3 + 0] = make_float4(R.o.x, R.o.y, R.o.z, time);
         ctx[lane * 3 + 1] = make_float4(R.d.x, R.d.y, R.d.z, q_min);
         ctx[lane * 3 + 2] = make_float4(R.inv_d.x, R.inv_d.y, R.inv_d.z, q_max);
@@ -73,7 +73,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
     __builtin_amdgcn_wave_barrier();
 
     uint32_t cur = COOP_NONE; // 26-bit node/leaf encoding of the entry this worker holds
-    int ray = 0, cray = -1;
+    int ray = 0, cray = -1, aray = -1; // ray of the held entry; ray whose context / whose a, inv_a are loaded
     float tent = 0.0f;
     RayF W;                   // context of ray `cray`
     W.o = f3(0, 0, 0); W.d = f3(0, 0, 1); W.inv_d = f3(0, 0, 0); W.a = 1.0f; W.inv_a = 1.0f;
@@ -108,9 +108,10 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
                 W.o = f3(c0.x, c0.y, c0.z); wtime = c0.w;
                 W.d = f3(c1.x, c1.y, c1.z); wqmin = c1.w;
                 W.inv_d = f3(c2.x, c2.y, c2.z); wqmax = c2.w;
-                W.a = dot(W.d, W.d);
-                W.inv_a = 1.0f / W.a;
-                wmabs = scale * (1.0f / 8192.0f) * __builtin_sqrtf(W.inv_a);
+                // pruning margin scale/8192/|d|, over-estimated (never under: pruning less is always safe) by
+                // 1/|d| <= min_i 1/|d_i| — no division, no square root on a context switch
+                wmabs = scale * (1.0f / 8192.0f) *
+                        fminf(fminf(__builtin_fabsf(W.inv_d.x), __builtin_fabsf(W.inv_d.y)), __builtin_fabsf(W.inv_d.z));
                 cray = ray;
             }
             // the ray's best hit so far -> pruning limit
@@ -146,6 +147,11 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
                 const int idx = (int)(cur & 0x003fffffu);
                 float t;
                 int pf;
+                if (type <= RTMI_PRIM_MSPHERE && aray != ray) { // sphere.rs:40 needs d.d
+                    W.a = dot(W.d, W.d);
+                    W.inv_a = 1.0f / W.a;
+                    aray = ray;
+                }
                 if (prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf)) {
                     const unsigned long long k = ((unsigned long long)f2sort(t) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)pf);
                     atomicMin(&best[ray], k);
