@@ -100,7 +100,7 @@ typedef struct {
 typedef struct {
     float lmin[3], lmax[3], rmin[3], rmax[3];
     int32_t left, right;
-    int32_t pad[2];
+    int32_t pad[2]; /* reserved: ignored on input (the library's device copy keeps derived child references here) */
 } rtmi_bvh_node; /* 64 B */
 #define RTMI_LEAF(type, prim) ((int32_t)(0x80000000u | ((uint32_t)(type) << 28) | (uint32_t)(prim)))
 

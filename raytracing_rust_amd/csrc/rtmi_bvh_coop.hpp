@@ -32,12 +32,9 @@ __device__ __forceinline__ uint32_t f2sort(float f) {
 __device__ __forceinline__ float sort2f(uint32_t s) {
     return __uint_as_float((s & 0x80000000u) ? (s & 0x7fffffffu) : ~s);
 }
-// node child reference (rtmi_bvh_node.left/right) -> 26-bit pool encoding
-__device__ __forceinline__ uint32_t coop_enc(int ref) {
-    if (ref >= 0) return (uint32_t)ref;
-    const uint32_t u = (uint32_t)ref;
-    return (1u << 25) | (((u >> 28) & 7u) << 22) | (u & 0x003fffffu);
-}
+// Pool encoding of a node child reference (26 bits, the ray id takes the upper 6): an internal node is its index
+// (< 2^25); a leaf is 1<<25 | type<<22 | primitive (< 2^22).  rtmi_scene_create stores both children of every
+// node in this encoding in the node record's reserved words.
 
 // All 64 lanes must call this together.  LDS layout for this wave (uint32 words):
 //   pool [cap][2] | ctx [64][12] floats | best [64] uint64
@@ -126,7 +123,8 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
             } else if (!(cur & (1u << 25))) { // internal node
                 const float4 *n = sc.nodes + (size_t)cur * 4;
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-                const int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+                // child references in pool encoding (filled in by rtmi_scene_create from left/right = n3.x, n3.y)
+                const uint32_t left = __float_as_uint(n3.z), right = __float_as_uint(n3.w);
                 float tl, tr;
                 bool vl = aabb_hit_t(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, W, wqmin, wqmax, tl);
                 bool vr = aabb_hit_t(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, W, wqmin, wqmax, tr);
@@ -135,12 +133,12 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
                 if (vl && vr) {
                     const bool lfirst = !(tr < tl);
                     push = true;
-                    push_ref = coop_enc(lfirst ? right : left);
+                    push_ref = lfirst ? right : left;
                     push_t = lfirst ? tr : tl;
-                    cur = coop_enc(lfirst ? left : right);
+                    cur = lfirst ? left : right;
                     tent = lfirst ? tl : tr;
-                } else if (vl) { cur = coop_enc(left); tent = tl; }
-                else if (vr) { cur = coop_enc(right); tent = tr; }
+                } else if (vl) { cur = left; tent = tl; }
+                else if (vr) { cur = right; tent = tr; }
                 else cur = COOP_NONE;
             } else { // leaf
                 const int type = (int)((cur >> 22) & 7u);

@@ -170,7 +170,18 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_a), d->n_prims, &s->dev.prim_a);
     if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_b), d->n_prims, &s->dev.prim_b);
     if (!rc) rc = upload(s, d->prim_meta, d->n_prims, &s->dev.meta);
-    if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->nodes), (size_t)d->n_nodes * 4, &nodes4);
+    if (!rc) {
+        // device copy of the nodes: the reserved words carry the child references in the 26-bit encoding of the
+        // cooperative traversal's work pool (rtmi_bvh_coop.hpp), so a node visit does not re-encode them
+        std::vector<rtmi_bvh_node> nodes(d->nodes, d->nodes + d->n_nodes);
+        const auto enc = [](int32_t ref) -> int32_t {
+            if (ref >= 0) return ref;
+            const uint32_t u = (uint32_t)ref;
+            return (int32_t)((1u << 25) | (((u >> 28) & 7u) << 22) | (u & 0x003fffffu));
+        };
+        for (rtmi_bvh_node &n : nodes) { n.pad[0] = enc(n.left); n.pad[1] = enc(n.right); }
+        rc = upload(s, reinterpret_cast<const float4 *>(nodes.data()), (size_t)d->n_nodes * 4, &nodes4);
+    }
     if (!rc) rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms);
     if (!rc) rc = upload(s, d->materials, d->n_materials, &s->dev.mats);
     if (!rc) rc = upload(s, d->textures, d->n_textures, &s->dev.texs);
