@@ -94,6 +94,27 @@ __device__ __forceinline__ bool sphere_test(const RayF &r, F3 c, float radius, f
     }
     return false;
 }
+// ConstantMedium::hit's two boundary queries (medium.rs:29-30) against ONE static sphere:
+//   boundary.hit(ray, -MAX, MAX) -> t1, then boundary.hit(ray, t1 + 0.0001, MAX) -> t2.
+// Both evaluate the same roots; sphere_test's conditions are applied to them twice, in its order.
+__device__ __forceinline__ void sphere_two_queries(const RayF &r, float4 A, bool &h1, float &t1, bool &h2, float &t2) {
+    const F3 oc = r.o - f3(A.x, A.y, A.z);
+    const float b = dot(oc, r.d);
+    const float cc = dot(oc, oc) - A.w * A.w;
+    const float disc = b * b - r.a * cc;
+    h1 = false; h2 = false;
+    if (disc > 0.0f) {
+        const float sq = __builtin_sqrtf(disc);
+        const float ta = (-b - sq) * r.inv_a, tb = (-b + sq) * r.inv_a;
+        if (ta < RTMI_FLT_MAX && ta > -RTMI_FLT_MAX) { t1 = ta; h1 = true; }
+        else if (tb < RTMI_FLT_MAX && tb > -RTMI_FLT_MAX) { t1 = tb; h1 = true; }
+        if (h1) {
+            const float lo = t1 + 0.0001f;
+            if (ta < RTMI_FLT_MAX && ta > lo) { t2 = ta; h2 = true; }
+            else if (tb < RTMI_FLT_MAX && tb > lo) { t2 = tb; h2 = true; }
+        }
+    }
+}
 // MovingSphere::center — src/sphere.rs:115-118 (contract: (time - t0) * inv_dt)
 __device__ __forceinline__ F3 moving_center(float4 A, float4 B, float inv_dt, float time) {
     float f = (time - B.w) * inv_dt;

@@ -208,8 +208,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     // ConstantMedium::hit — medium.rs:28-56
                     float t1 = 0.0f, t2 = 0.0f, tm;
                     int pf;
-                    const bool h1 = geom_query_coop<PROF>(sc, I, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, wlds, cap, t1, pf, overflow, prof, slot);
-                    const bool h2 = geom_query_coop<PROF>(sc, I, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, wlds, cap, t2, pf, overflow, prof, slot);
+                    bool h1, h2;
+                    if (I.kind == RTMI_ITEM_LIST && I.count == 1 && sc.meta[I.first].type == RTMI_PRIM_SPHERE) {
+                        // boundary = one static sphere (wave-uniform test): both boundary queries are roots of the
+                        // same quadratic, evaluated once (same expressions as two Sphere::hit calls: same bits)
+                        h1 = false; h2 = false;
+                        if (need) sphere_two_queries(R, sc.prim_a[I.first], h1, t1, h2, t2);
+                    } else {
+                        h1 = geom_query_coop<PROF>(sc, I, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, wlds, cap, t1, pf, overflow, prof, slot);
+                        h2 = geom_query_coop<PROF>(sc, I, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, wlds, cap, t2, pf, overflow, prof, slot);
+                    }
                     if (need && h1 && h2) {
                         if (medium_sample(t1, t2, P.t_min, closest, W.d, I.neg_inv_density, g, k0, k1, tm)) {
                             closest = tm; best_item = (int)it; best_medium = true;
