@@ -261,7 +261,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
 }
 
 // ----------------------------------------------------------------------------------
-// render kernel, asynchronous form (default).
+// render kernel, asynchronous form (RTMI_FLAG_ASYNC; a measured negative result kept as an independent
+// implementation for the parity tests: bit-identical, ~0.7x the two-phase kernels).
 //
 // Measured on the synchronous kernel: inside BVH traversal only 4-10 % of the lanes are active
 // per iteration (a few lanes walk long while the rest have already left the tree), because the
