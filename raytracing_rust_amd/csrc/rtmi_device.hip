@@ -1,14 +1,15 @@
 // rtmi_device.hip — gfx950 (MI355X, CDNA4) device path of the per-pixel render loop.
 //
-// One wavefront (64 lanes) renders one 8x8 pixel tile for one chunk of the sample range:
-// lane = pixel.  Every lane runs its own `for s in 0..ns` loop (tests/test.rs:65-70) with
-// path regeneration: a lane whose path ended immediately starts its next sample, so all
-// 64 lanes stay busy in the bounce loop although path lengths differ (1..51 hit queries,
-// src/color.rs:6-23).  The recursion of `color` is unrolled into the throughput form
-// L += T*emitted; T *= attenuation.  Random numbers are Philox4x32-10 counter streams
-// keyed per (pixel, sample), so the result is independent of tiling, chunking and the
-// number of GPUs.  BVH traversal keeps a per-lane stack in LDS (runtime-indexed per-lane
-// arrays would spill to scratch).  No MFMA: there is no dense contraction on this path.
+// Persistent wavefronts (256 CUs x 16) take units = (8x8 pixel tile, 16 samples) from a global counter; the
+// 64 lanes of a wavefront take (sample, pixel) items of its unit dynamically: a lane whose path ended
+// starts the next item at once, whatever its pixel, so all lanes stay busy although path lengths differ
+// (1..51 hit queries, src/color.rs:6-23).  Every finished path stores its radiance in a per-sample
+// buffer in HBM; a resolve kernel adds the samples of a pixel in sample order (tests/test.rs:65-70).
+// The recursion of `color` is unrolled into the throughput form L += T*emitted; T *= attenuation.
+// Random numbers are Philox4x32-10 counter streams keyed per (pixel, sample), so the result is
+// independent of scheduling, tiling, unit size and the number of GPUs.  BVH traversal is cooperative:
+// the lanes are workers on a wave-shared LIFO of (ray, node) entries in LDS (rtmi_bvh_coop.hpp).
+// No MFMA: there is no dense contraction on this path.
 //
 // Arithmetic follows the fp32 contract of DESIGN.md: op order as written here, no FMA
 // contraction (-ffp-contract=off), IEEE / and sqrt, transcendental functions from
