@@ -36,14 +36,27 @@ __device__ __forceinline__ float sort2f(uint32_t s) {
 // (< 2^25); a leaf is 1<<25 | type<<22 | primitive (< 2^22).  rtmi_scene_create stores both children of every
 // node in this encoding in the node record's reserved words.
 
-// All 64 lanes must call this together.  LDS layout for this wave (uint32 words):
-//   pool [cap][2] | ctx [64][12] floats | best [64] uint64
+// Work space of one wavefront.  LDS (uint32 words): pool [cap][2] | ctx [64][12] floats | best [64] uint64.
+// The pool in LDS is the TOP of the logical LIFO; when it runs full its older half moves to `spill` (global
+// memory, private to the wavefront) and comes back when the LDS part is empty, so the logical stack and
+// its depth-first bound of 64 * (tree depth + 1) entries are unchanged while the LDS footprint does not
+// depend on the tree depth.
+struct CoopWork {
+    uint32_t *wlds;
+    int cap;        // LDS pool entries (multiple of 64, >= 256)
+    uint2 *spill;   // global part of the stack
+    int spill_cap;  // its capacity in entries: 64 * (deepest tree + 2)
+};
+
+// All 64 lanes must call this together.
 template <bool PROF>
 __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, float scale, bool active, const RayF &R,
-                                               float time, float q_min, float q_max, uint32_t *wlds, int cap,
+                                               float time, float q_min, float q_max, const CoopWork &cw,
                                                bool &have, float &t_out, int &pf_out, bool &overflow,
                                                unsigned long long *prof, int slot) {
     const int lane = threadIdx.x & 63;
+    uint32_t *wlds = cw.wlds;
+    const int cap = cw.cap;
     // Plain (non-volatile) LDS accesses: every exchange between lanes is separated by a wavefront-scope
     // fence + wave barrier, and plain accesses let the compiler keep the LDS address space (ds_read/write_b64;
     // volatile ones became flat loads/stores with a full wait each — five per iteration).
@@ -65,7 +78,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
         const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u));
         pool[pos] = make_uint2(((uint32_t)lane << 26) | (uint32_t)root, __float_as_uint(q_min)); // root entry distance: conservative
     }
-    int top = __popcll(m_act);
+    int top = __popcll(m_act), gtop = 0; // entries in the LDS part / in the spilled (older) part of the stack
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -76,13 +89,17 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
     W.o = f3(0, 0, 0); W.d = f3(0, 0, 1); W.inv_d = f3(0, 0, 0); W.a = 1.0f; W.inv_a = 1.0f;
     float wtime = 0.0f, wqmin = 0.0f, wqmax = 0.0f, wmabs = 0.0f;
 
+    // The hot loop runs until the LDS part is empty with all workers idle, or too full for 64 more pushes; the
+    // rare handling of both (refill from / spill to global memory) sits in the outer loop, outside the hot
+    // loop's register allocation.
+    for (;;) {
     for (;;) {
         // ---- idle workers take the deepest pending entries
         const bool needw = cur == COOP_NONE;
         const unsigned long long m_need = __ballot(needw);
         const int n_need = __popcll(m_need);
         if (top == 0 && n_need == 64) break;
-        if (top > cap - 64) { overflow = true; break; }
+        if (top > cap - 64) break;
         const int take = n_need < top ? n_need : top;
         if (needw) {
             const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
@@ -164,6 +181,32 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
             pool[pos] = make_uint2(((uint32_t)ray << 26) | push_ref, __float_as_uint(push_t));
         }
         top += __popcll(m_push);
+        if (PROF && lane == 0) atomicMax(&prof[2 * 18], (unsigned long long)top); // deepest pool seen (diagnostics)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+        if (top > cap - 64) { // no room for 64 pushes: the older half goes to global memory, order kept
+            const int m = (top / 2) & ~63;
+            if (gtop + m > cw.spill_cap) { overflow = true; break; } // cannot happen by the depth-first bound
+            for (int i = lane; i < m; i += 64) cw.spill[gtop + i] = pool[i];
+            const int rest = top - m;
+            for (int base = 0; base < rest; base += 64) { // slide the newer part down; chunk k writes [64k, 64k+64)
+                const int i = base + lane;                // and later chunks read above m + 64k + 64: no overlap
+                uint2 e = make_uint2(0u, 0u);
+                if (i < rest) e = pool[m + i];
+                __builtin_amdgcn_wave_barrier();
+                if (i < rest) pool[i] = e;
+            }
+            gtop += m;
+            top = rest;
+        } else if (gtop > 0) { // LDS part empty, every worker idle: bring back the newest spilled entries
+            const int n = gtop < cap / 2 ? gtop : cap / 2;
+            for (int i = lane; i < n; i += 64) pool[i] = cw.spill[gtop - n + i];
+            gtop -= n;
+            top = n;
+        } else {
+            break; // nothing pending anywhere
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
@@ -183,7 +226,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
 // geometry of one item for the whole wavefront: every lane calls it; `active` lanes own a query
 template <bool PROF>
 __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_item &I, bool active, const RayF &r,
-                                                float time, float q_min, float q_max, uint32_t *wlds, int cap,
+                                                float time, float q_min, float q_max, const CoopWork &cw,
                                                 float &t_out, int &pf_out, bool &overflow, unsigned long long *prof,
                                                 int slot) {
     if (I.kind == RTMI_ITEM_BVH) { // wave-uniform branch
@@ -191,7 +234,7 @@ __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_i
         const bool enter = active && aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
                                               I.root_max[2], r, q_min, q_max);
         bool have = false;
-        coop_bvh_query<PROF>(sc, I.first, I.scale, enter, r, time, q_min, q_max, wlds, cap, have, t_out, pf_out, overflow,
+        coop_bvh_query<PROF>(sc, I.first, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow,
                              prof, slot);
         return have;
     }

@@ -51,6 +51,8 @@ struct rtmi_scene {
     size_t partial_bytes = 0;
     float4 *samples = nullptr; // per-sample radiance [local tile][pass samples][64]
     size_t samples_bytes = 0;
+    uint2 *spill = nullptr;    // global part of the cooperative traversal stacks [wavefront slot][spill_cap]
+    size_t spill_bytes = 0;
     unsigned int *status = nullptr; // device words: [0] cooperative-traversal pool overflows (must stay 0),
                                     // [1] unit counter of the persistent wavefronts
     int slots = 0;                  // CUs x 16: resident wavefronts the render kernels are launched with
@@ -220,6 +222,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->partial) (void)hipFree(s->partial);
     if (s->samples) (void)hipFree(s->samples);
+    if (s->spill) (void)hipFree(s->spill);
     if (s->texels) (void)hipFree(s->texels);
     if (s->status) (void)hipFree(s->status);
     for (int i = 0; i < 3; i++)
@@ -376,7 +379,21 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     P.status = s->status;
     P.queue = s->status + 1;
     P.sky = (p->flags & RTMI_FLAG_SKY) ? 1u : 0u;
-    P.coop_cap = 64u * (s->meta.max_bvh_depth + 2u);
+    // LDS part of the traversal stack: 512 entries cover the deepest stack ever seen on the reference scenes
+    // (447); deeper stacks continue in global memory (64 * (depth + 2) entries per wavefront, the bound of the
+    // depth-first order), so the LDS footprint (7.7 KB per wavefront) does not depend on the tree depth
+    P.coop_cap = 512u;
+    if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
+    P.spill_cap = 64u * (s->meta.max_bvh_depth + 2u);
+    if (coop) {
+        const size_t spill_bytes = (size_t)s->slots * P.spill_cap * sizeof(uint2);
+        if (spill_bytes > s->spill_bytes) {
+            if (s->spill) { HIP_TRY(hipFree(s->spill)); s->spill = nullptr; s->spill_bytes = 0; }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->spill), spill_bytes));
+            s->spill_bytes = spill_bytes;
+        }
+    }
+    P.spill = s->spill;
     const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u) * sizeof(uint32_t);
     const uint32_t ntex = P.ntiles_local * 64u;
     uint32_t blocks_total = 0, chunks_total = 0;

@@ -146,8 +146,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[]; // per wave: pool | ctx | best
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int cap = (int)P.coop_cap;
-    uint32_t *wlds = lds_dyn + (size_t)wave * (2u * cap + 64u * 12u + 128u);
+    CoopWork cw;
+    cw.cap = (int)P.coop_cap;
+    cw.wlds = lds_dyn + (size_t)wave * (2u * cw.cap + 64u * 12u + 128u);
+    cw.spill_cap = (int)P.spill_cap;
+    cw.spill = P.spill + (size_t)(blockIdx.x * WAVES_PER_BLOCK + wave) * P.spill_cap;
     unsigned long long sig = 0ull;
     WaveWork w;
     w.ltile = 0u; w.ps_base = 0u; w.obase = 0u; w.x0 = 0u; w.y0 = 0u; w.cols = 0u; w.n_valid = 0u; w.next = 0u; w.total = 0u;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                     float t;
                     int pf;
-                    if (geom_query_coop<PROF>(sc, I, need, R, pa.rtime, P.t_min, closest, wlds, cap, t, pf, overflow, prof, slot)) {
+                    if (geom_query_coop<PROF>(sc, I, need, R, pa.rtime, P.t_min, closest, cw, t, pf, overflow, prof, slot)) {
                         closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                     }
                     prof_time<PROF>(prof, I.kind == RTMI_ITEM_BVH ? (it == 0 ? 27 : 28) : 26, tstamp);
@@ -215,8 +218,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         h1 = false; h2 = false;
                         if (need) sphere_two_queries(R, sc.prim_a[I.first], h1, t1, h2, t2);
                     } else {
-                        h1 = geom_query_coop<PROF>(sc, I, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, wlds, cap, t1, pf, overflow, prof, slot);
-                        h2 = geom_query_coop<PROF>(sc, I, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, wlds, cap, t2, pf, overflow, prof, slot);
+                        h1 = geom_query_coop<PROF>(sc, I, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
+                        h2 = geom_query_coop<PROF>(sc, I, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
                     }
                     if (need && h1 && h2) {
                         if (medium_sample(t1, t2, P.t_min, closest, W.d, I.neg_inv_density, g, k0, k1, tm)) {
@@ -256,7 +259,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
 
     if (PROF) {
         __syncthreads();
-        if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
+        if (threadIdx.x < 2 * RTMI_PROF_SLOTS && prof_lds[threadIdx.x] != 0ull) {
+            if (threadIdx.x == 2 * 18) atomicMax(P.prof + threadIdx.x, prof_lds[threadIdx.x]); // slot 18: a maximum
+            else atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
+        }
     }
 }
 

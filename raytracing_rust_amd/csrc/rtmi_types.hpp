@@ -65,7 +65,9 @@ struct DevParams {
     unsigned long long *prof;
     uint32_t stack_depth;
     uint32_t shade_threshold;
-    uint32_t coop_cap;
+    uint32_t coop_cap;   // entries of the cooperative traversal's LDS pool
+    uint32_t spill_cap;  // entries per wavefront of its global-memory extension
+    uint2 *spill;
     unsigned int *status;
     unsigned int *queue; // next unit of the persistent wavefronts (zeroed before every launch)
     uint32_t sky; // RTMI_FLAG_SKY

@@ -142,3 +142,17 @@ def test_golden_black_scenes_800(host):
         cam, world = scenes.build(host, name, 800, 800, seed=1)
         img = host.lower(world).render(cam, 800, 800, 4, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
         assert hashlib.sha256(ppm_p3(img["rgb8"])).hexdigest() == gold
+
+
+@pytest.mark.parametrize("name,nx,ny,ns", [("final_scene", 160, 96, 16), ("lit_final_scene", 160, 96, 16),
+                                            ("lit_random_spheres", 152, 104, 16)])
+def test_traversal_stack_spill_to_global_memory(host, name, nx, ny, ns):
+    """The cooperative traversal keeps the top of its work stack in LDS and the rest in global memory.  Flag
+    bit 11 (test knob) shrinks the LDS part to 256 entries, so it spills and refills all the time: same bits."""
+    cam, world = scenes_extra.build(host, name, nx, ny, seed=1)
+    sc = host.lower(world)
+    exact = sc.render(cam, nx, ny, ns, seed=42, flags=0, sig=True)
+    for flags in (abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | (1 << 11)):
+        got = sc.render(cam, nx, ny, ns, seed=42, flags=flags, sig=True)
+        assert np.array_equal(exact["sig"], got["sig"]), flags
+        assert np.array_equal(exact["linear"], got["linear"]), flags

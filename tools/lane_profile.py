@@ -29,6 +29,8 @@ def run(name, nx, ny, ns, flags, threshold=0):
     print("== %s %dx%dx%d flags=%d  kernel %.1f ms (profiling build)" % (name, nx, ny, ns, flags, st["render_ms"]))
     samples = nx * ny * ns
     tot_wave = 0
+    print("  deepest cooperative pool: %d entries (capacity 64 x (max BVH depth + 2) = %d)" % (int(c[2 * 18]), 64 * (sc.arrays()["max_bvh_depth"] + 2)))
+    c[2 * 18] = 0
     for s in range(32):
         act, wav = int(c[2 * s]), int(c[2 * s + 1])
         if wav == 0:
