@@ -31,6 +31,9 @@ pub struct FlatScene {
     pub prim_a: Vec<f32>,
     pub prim_b: Vec<f32>,
     pub prim_meta: Vec<RtmiPrimMeta>,
+    /// optional: 8 floats per primitive (include/rtmi.h, prim_gate); empty = none
+    pub prim_gate: Vec<f32>,
+    pub alt_max_depth: u32,
     pub nodes: Vec<RtmiBvhNode>,
     pub xforms: Vec<RtmiXform>,
     pub materials: Vec<RtmiMaterial>,
@@ -56,6 +59,8 @@ impl FlatScene {
             prim_a: self.prim_a.as_ptr(),
             prim_b: self.prim_b.as_ptr(),
             prim_meta: self.prim_meta.as_ptr(),
+            prim_gate: if self.prim_gate.is_empty() { std::ptr::null() } else { self.prim_gate.as_ptr() },
+            alt_max_depth: self.alt_max_depth,
             n_nodes: self.nodes.len() as u32,
             nodes: self.nodes.as_ptr(),
             n_xforms: self.xforms.len() as u32,

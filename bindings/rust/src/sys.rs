@@ -4,13 +4,14 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTMI_ABI_VERSION: u32 = 2;
+pub const RTMI_ABI_VERSION: u32 = 3;
 pub const RTMI_FLAG_FAST_CULL: u32 = 1;
 pub const RTMI_FLAG_PATH_SIG: u32 = 2;
 pub const RTMI_FLAG_PROFILE: u32 = 4;
 pub const RTMI_FLAG_SYNC: u32 = 8;
 pub const RTMI_FLAG_ASYNC: u32 = 16;
 pub const RTMI_FLAG_SKY: u32 = 32;
+pub const RTMI_FLAG_REF_TREE: u32 = 64;
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -93,7 +94,7 @@ pub struct RtmiItem {
     pub root_min: [f32; 3],
     pub root_max: [f32; 3],
     pub scale: f32,
-    pub pad: i32,
+    pub alt_first: i32,
 }
 
 #[repr(C)]
@@ -105,6 +106,8 @@ pub struct RtmiSceneDesc {
     pub prim_a: *const f32,
     pub prim_b: *const f32,
     pub prim_meta: *const RtmiPrimMeta,
+    pub prim_gate: *const f32,
+    pub alt_max_depth: u32,
     pub n_nodes: u32,
     pub nodes: *const RtmiBvhNode,
     pub n_xforms: u32,

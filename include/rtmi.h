@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 2u
+#define RTMI_ABI_VERSION 3u
 #define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
 #define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
 
@@ -130,7 +130,7 @@ typedef struct {
     float scale;             /* BVH: largest |coordinate| of the root box (fast-cull margins only); 1e30 = never prune
                               * (a BVH whose boxes do not contain their primitives, e.g. Rect::bounding_box of a
                               * YZ/ZX rect, rect.rs:71-75: pruned traversal then visits what BVHNode::hit visits) */
-    int32_t pad;
+    int32_t alt_first;       /* BVH: root of the alternative tree over the same primitives (see prim_gate), or -1 */
 } rtmi_item; /* 64 B */
 
 typedef struct {
@@ -141,6 +141,16 @@ typedef struct {
     const float *prim_a; /* n_prims * 4 */
     const float *prim_b; /* n_prims * 4 */
     const rtmi_prim_meta *prim_meta;
+    /* Optional (NULL = none): per primitive the box of its PARENT BVHNode in the reference tree, 8 floats
+     * {min.xyz, 0, max.xyz, 0}.  BVHNode::hit (bvh.rs:70-73) reaches a leaf iff every ancestor's box passes
+     * AABB::hit with the query's (t_min, t_max); the slab test is monotone in the box, so that is equivalent
+     * to the parent's box passing.  With this "gate" any conservative tree over the same primitives (an item's
+     * alt_first: a SAH tree on the primitives' true extents) returns the reference's result bit for bit:
+     * accept a primitive iff its own test AND its gate pass, keep the minimum t, ties -> larger primitive
+     * index (= rightmost leaf of the reference tree).  Used by the cooperative kernel; the exact and per-lane
+     * kernels walk the reference tree (items' first). */
+    const float *prim_gate;
+    uint32_t alt_max_depth; /* deepest alternative tree (sizes the traversal stack's global part) */
     uint32_t n_nodes;
     const rtmi_bvh_node *nodes;
     uint32_t n_xforms;
@@ -173,6 +183,7 @@ typedef struct {
 #define RTMI_FLAG_PROFILE 4u   /* diagnostics build: lane-activity counters into prof (64 uint64); slow */
 #define RTMI_FLAG_SYNC 8u      /* per-lane BVH traversal instead of the wave-cooperative one (exact mode always is) */
 #define RTMI_FLAG_ASYNC 16u    /* per-lane state-machine kernel (experimental, kept for comparison) */
+#define RTMI_FLAG_REF_TREE 64u /* cooperative kernel: walk the reference-topology tree, not the alternative one */
 #define RTMI_FLAG_SKY 32u      /* opt-in extension, off by default: a ray that misses the world returns the gradient
                                 * the reference keeps commented out at src/color.rs:18-20 instead of black (:21) */
 typedef struct {

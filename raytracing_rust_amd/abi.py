@@ -9,7 +9,7 @@ import os
 
 from . import build as _build
 
-RTMI_ABI_VERSION = 2
+RTMI_ABI_VERSION = 3
 RTMI_MAX_BVH_DEPTH = 24
 RTMI_TILE = 8
 RTMI_FLAG_FAST_CULL = 1
@@ -18,6 +18,7 @@ RTMI_FLAG_PROFILE = 4
 RTMI_FLAG_SYNC = 8
 RTMI_FLAG_ASYNC = 16
 RTMI_FLAG_SKY = 32
+RTMI_FLAG_REF_TREE = 64
 
 TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
@@ -61,13 +62,13 @@ class Item(C.Structure):
     _fields_ = [("kind", C.c_int32), ("first", C.c_int32), ("count", C.c_int32), ("flags", C.c_uint32),
                 ("xform_first", C.c_int32), ("xform_count", C.c_int32), ("medium_material", C.c_int32),
                 ("neg_inv_density", C.c_float), ("root_min", C.c_float * 3), ("root_max", C.c_float * 3),
-                ("scale", C.c_float), ("pad", C.c_int32)]
+                ("scale", C.c_float), ("alt_first", C.c_int32)]
 
 
 class SceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("n_items", C.c_uint32), ("items", C.POINTER(Item)),
                 ("n_prims", C.c_uint32), ("prim_a", C.POINTER(C.c_float)), ("prim_b", C.POINTER(C.c_float)),
-                ("prim_meta", C.POINTER(PrimMeta)),
+                ("prim_meta", C.POINTER(PrimMeta)), ("prim_gate", C.POINTER(C.c_float)), ("alt_max_depth", C.c_uint32),
                 ("n_nodes", C.c_uint32), ("nodes", C.POINTER(BvhNode)),
                 ("n_xforms", C.c_uint32), ("xforms", C.POINTER(Xform)),
                 ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),

@@ -50,7 +50,7 @@ struct CoopWork {
 
 // All 64 lanes must call this together.
 template <bool PROF>
-__device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, float scale, bool active, const RayF &R,
+__device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, bool gated, float scale, bool active, const RayF &R,
                                                float time, float q_min, float q_max, const CoopWork &cw,
                                                bool &have, float &t_out, int &pf_out, bool &overflow,
                                                unsigned long long *prof, int slot) {
@@ -167,7 +167,12 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
                     W.inv_a = 1.0f / W.a;
                     aray = ray;
                 }
-                if (prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf)) {
+                bool hit = prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf);
+                if (hit && gated) { // alternative tree: the reference reaches this leaf iff its parent's box passes
+                    const float4 g0 = sc.gate[idx * 2], g1 = sc.gate[idx * 2 + 1];
+                    hit = aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, W, wqmin, wqmax);
+                }
+                if (hit) {
                     const unsigned long long k = ((unsigned long long)f2sort(t) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)pf);
                     atomicMin(&best[ray], k);
                 }
@@ -225,7 +230,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, flo
 
 // geometry of one item for the whole wavefront: every lane calls it; `active` lanes own a query
 template <bool PROF>
-__device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_item &I, bool active, const RayF &r,
+__device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_item &I, bool use_alt, bool active, const RayF &r,
                                                 float time, float q_min, float q_max, const CoopWork &cw,
                                                 float &t_out, int &pf_out, bool &overflow, unsigned long long *prof,
                                                 int slot) {
@@ -234,7 +239,8 @@ __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_i
         const bool enter = active && aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
                                               I.root_max[2], r, q_min, q_max);
         bool have = false;
-        coop_bvh_query<PROF>(sc, I.first, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow,
+        const bool alt = use_alt && I.alt_first >= 0;
+        coop_bvh_query<PROF>(sc, alt ? I.alt_first : I.first, alt, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow,
                              prof, slot);
         return have;
     }

@@ -115,6 +115,8 @@ static int validate(const rtmi_scene_desc *d) {
                 return fail(RTMI_ERR_INVALID, "item primitive range out of bounds");
         } else if (it.kind == RTMI_ITEM_BVH) {
             if (it.first < 0 || (uint32_t)it.first >= d->n_nodes) return fail(RTMI_ERR_INVALID, "item BVH root out of range");
+            if (it.alt_first >= 0 && ((uint32_t)it.alt_first >= d->n_nodes || !d->prim_gate))
+                return fail(RTMI_ERR_INVALID, "item alternative tree out of range or prim_gate missing");
         } else {
             return fail(RTMI_ERR_INVALID, "bad item kind");
         }
@@ -173,6 +175,7 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_a), d->n_prims, &s->dev.prim_a);
     if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_b), d->n_prims, &s->dev.prim_b);
     if (!rc) rc = upload(s, d->prim_meta, d->n_prims, &s->dev.meta);
+    if (!rc && d->prim_gate) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_gate), (size_t)d->n_prims * 2, &s->dev.gate);
     if (!rc) {
         // device copy of the nodes: the reserved words carry the child references in the 26-bit encoding of the
         // cooperative traversal's work pool (rtmi_bvh_coop.hpp), so a node visit does not re-encode them
@@ -384,7 +387,9 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     // depth-first order), so the LDS footprint (7.7 KB per wavefront) does not depend on the tree depth
     P.coop_cap = 512u;
     if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
-    P.spill_cap = 64u * (s->meta.max_bvh_depth + 2u);
+    P.use_alt = (s->dev.gate != nullptr && !(p->flags & RTMI_FLAG_REF_TREE)) ? 1u : 0u;
+    const uint32_t deepest = s->meta.alt_max_depth > s->meta.max_bvh_depth ? s->meta.alt_max_depth : s->meta.max_bvh_depth;
+    P.spill_cap = 64u * (deepest + 2u);
     if (coop) {
         const size_t spill_bytes = (size_t)s->slots * P.spill_cap * sizeof(uint2);
         if (spill_bytes > s->spill_bytes) {

@@ -38,6 +38,7 @@ struct DevScene {
     const float4 *prim_a;
     const float4 *prim_b;
     const rtmi_prim_meta *meta;
+    const float4 *gate;  // 2 x float4 per primitive: box of its parent BVHNode in the reference tree (or NULL)
     const float4 *nodes; // 4 x float4 per rtmi_bvh_node
     const rtmi_xform *xforms;
     const rtmi_material *mats;
@@ -71,4 +72,5 @@ struct DevParams {
     unsigned int *status;
     unsigned int *queue; // next unit of the persistent wavefronts (zeroed before every launch)
     uint32_t sky; // RTMI_FLAG_SKY
+    uint32_t use_alt; // cooperative kernel: walk the items' alternative trees, leaves accepted through their gate
 };

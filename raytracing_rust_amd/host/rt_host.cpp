@@ -583,6 +583,11 @@ int SceneBuilder::push_prim(const Hittable &h, bool flip, bool force_moving) {
     out.prim_a.insert(out.prim_a.end(), A, A + 4);
     out.prim_b.insert(out.prim_b.end(), B, B + 4);
     out.prim_meta.push_back(m);
+    const float big = 3.40282346638528859811704183484516925e+38f;
+    const float gate[8] = {-big, -big, -big, 0.0f, big, big, big, 0.0f}; // no gate unless a BVH sets one
+    out.prim_gate.insert(out.prim_gate.end(), gate, gate + 8);
+    out.prim_box.push_back(AABB(Vec3(0, 0, 0), Vec3(0, 0, 0)));
+    out.prim_has_box.push_back(0);
     return (int)out.prim_meta.size() - 1;
 }
 
@@ -680,6 +685,14 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
         } else {
             const int prim = push_prim(*h, flip, force_moving);
             child[c] = RTMI_LEAF(out.prim_meta[(size_t)prim].type, prim);
+            { // gate = the box of THIS node, the leaf's parent in the reference tree, rounded like every node box
+                float gmn[3], gmx[3];
+                put_box(gmn, gmx, n.bbox_);
+                float *g = &out.prim_gate[(size_t)prim * 8];
+                g[0] = gmn[0]; g[1] = gmn[1]; g[2] = gmn[2]; g[4] = gmx[0]; g[5] = gmx[1]; g[6] = gmx[2];
+                AABB tbx(Vec3(0, 0, 0), Vec3(0, 0, 0));
+                if (true_bounds(h, tbx)) { out.prim_box[(size_t)prim] = tbx; out.prim_has_box[(size_t)prim] = 1; }
+            }
             // A leaf child has no box test in the reference (bvh.rs:72-73).  The box stored here is
             // used only by the fast-cull prefilter, so it must contain every hit the primitive's own
             // fp32 test can report, at EVERY ray time: the exact box padded by `pad` for static
@@ -702,8 +715,105 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
     return id;
 }
 
+// Alternative tree over the primitives [lo,hi) of `prims` for the pruned kernels: binned SAH on the primitives'
+// TRUE extents, child boxes padded by `pad`.  Its boxes only cull; a primitive is accepted iff its own test
+// passes AND its gate passes (the box of its parent in the reference tree): BVHNode::hit reaches a leaf iff
+// every ancestor's box passes AABB::hit with the query's (t_min, t_max), the slab test is monotone in the box
+// and every ancestor's box contains the parent's, so that is equivalent to the parent's box passing.  With
+// "minimum t, ties -> larger primitive index" (primitives are numbered in the reference's leaf order) any
+// conservative tree therefore returns the reference's result bit for bit.  Returns a child reference and the
+// padded box of the subtree.
+static double box_area(const AABB &b) {
+    const double dx = b.max.x - b.min.x, dy = b.max.y - b.min.y, dz = b.max.z - b.min.z;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+}
+int32_t SceneBuilder::build_alt_tree(std::vector<int> &prims, size_t lo, size_t hi, uint32_t depth, double pad, AABB *box_out) {
+    const size_t n = hi - lo;
+    const Vec3 pd(pad, pad, pad);
+    if (n == 1) {
+        const int prim = prims[lo];
+        const AABB &b = out.prim_box[(size_t)prim];
+        *box_out = AABB(b.min - pd, b.max + pd);
+        return RTMI_LEAF(out.prim_meta[(size_t)prim].type, prim);
+    }
+    if (depth > out.alt_max_depth) out.alt_max_depth = depth;
+    auto centroid = [&](int p, int a) { const AABB &b = out.prim_box[(size_t)p]; return 0.5 * (b.min[a] + b.max[a]); };
+    size_t mid = lo + n / 2;
+    bool split_done = false;
+    if (depth < 40) { // SAH split; deeper than that (degenerate inputs) fall back to balanced medians
+        double best_cost = 1e300;
+        int best_axis = -1, best_bin = -1;
+        const int NB = 16;
+        double cmin[3] = {1e300, 1e300, 1e300}, cmax[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = lo; i < hi; i++)
+            for (int a = 0; a < 3; a++) { const double c = centroid(prims[i], a); cmin[a] = std::fmin(cmin[a], c); cmax[a] = std::fmax(cmax[a], c); }
+        for (int a = 0; a < 3; a++) {
+            if (!(cmax[a] - cmin[a] > 1e-12) || !(cmax[a] - cmin[a] < 1e30)) continue;
+            AABB bb[NB];
+            size_t cnt[NB] = {0};
+            bool used[NB] = {false};
+            const double scale = NB / (cmax[a] - cmin[a]);
+            for (size_t i = lo; i < hi; i++) {
+                int b = (int)((centroid(prims[i], a) - cmin[a]) * scale);
+                b = b < 0 ? 0 : (b >= NB ? NB - 1 : b);
+                bb[b] = used[b] ? surrounding_box(bb[b], out.prim_box[(size_t)prims[i]]) : out.prim_box[(size_t)prims[i]];
+                used[b] = true; cnt[b]++;
+            }
+            AABB lbox[NB], rbox[NB], run;
+            size_t lc[NB], rc[NB], acc = 0;
+            bool has = false;
+            for (int b = 0; b < NB; b++) { // prefix boxes / counts from the left
+                if (used[b]) { run = has ? surrounding_box(run, bb[b]) : bb[b]; has = true; }
+                lbox[b] = run; acc += cnt[b]; lc[b] = acc;
+            }
+            acc = 0; has = false;
+            for (int b = NB - 1; b >= 0; b--) { // suffix boxes / counts from the right
+                if (used[b]) { run = has ? surrounding_box(run, bb[b]) : bb[b]; has = true; }
+                rbox[b] = run; acc += cnt[b]; rc[b] = acc;
+            }
+            for (int b = 0; b < NB - 1; b++) {
+                if (lc[b] == 0 || rc[b + 1] == 0) continue;
+                const double cost = box_area(lbox[b]) * (double)lc[b] + box_area(rbox[b + 1]) * (double)rc[b + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
+            }
+        }
+        if (best_axis >= 0) {
+            const double scale = 16 / (cmax[best_axis] - cmin[best_axis]);
+            auto it = std::stable_partition(prims.begin() + (long)lo, prims.begin() + (long)hi, [&](int p) {
+                int b = (int)((centroid(p, best_axis) - cmin[best_axis]) * scale);
+                b = b < 0 ? 0 : (b >= 16 ? 15 : b);
+                return b <= best_bin;
+            });
+            mid = (size_t)(it - prims.begin());
+            split_done = mid > lo && mid < hi;
+        }
+    }
+    if (!split_done) { // balanced median split along the widest centroid axis
+        int axis = 0; double ext = -1.0;
+        for (int a = 0; a < 3; a++) {
+            double mn = 1e300, mx = -1e300;
+            for (size_t i = lo; i < hi; i++) { const double c = centroid(prims[i], a); mn = std::fmin(mn, c); mx = std::fmax(mx, c); }
+            if (mx - mn > ext && mx - mn < 1e30) { ext = mx - mn; axis = a; }
+        }
+        mid = lo + n / 2;
+        std::stable_sort(prims.begin() + (long)lo, prims.begin() + (long)hi, [&](int a, int b) { return centroid(a, axis) < centroid(b, axis); });
+    }
+    const int32_t id = (int32_t)out.nodes.size();
+    out.nodes.push_back(rtmi_bvh_node{});
+    AABB lb, rb;
+    const int32_t l = build_alt_tree(prims, lo, mid, depth + 1, pad, &lb);
+    const int32_t r = build_alt_tree(prims, mid, hi, depth + 1, pad, &rb);
+    rtmi_bvh_node &me = out.nodes[(size_t)id];
+    put_box(me.lmin, me.lmax, lb);
+    put_box(me.rmin, me.rmax, rb);
+    me.left = l; me.right = r;
+    *box_out = surrounding_box(lb, rb);
+    return id;
+}
+
 void SceneBuilder::lower_item(const Hittable &top) {
     rtmi_item it{};
+    it.alt_first = -1;
     it.xform_first = (int32_t)out.xforms.size();
     bool flip = false, medium = false;
     const Hittable *h = &top;
@@ -745,8 +855,18 @@ void SceneBuilder::lower_item(const Hittable &top) {
         bool any = false;
         const bool prunable = contained(*bvh, scale / 65536.0, tb, any);
         it.scale = prunable ? (float)scale : 1e30f; // 1e30: the pruning margin swallows every distance
+        const size_t prim_begin = out.prim_meta.size();
         it.first = lower_bvh(*bvh, 1, contains_moving(bvh), scale / 8192.0, !prunable);
         moving_time_range(bvh, out.bvh_time_lo, out.bvh_time_hi);
+        if (prunable) { // alternative (SAH) tree over the same primitives, traversed by the cooperative kernel
+            std::vector<int> prims;
+            for (size_t q = prim_begin; q < out.prim_meta.size(); q++)
+                if (out.prim_has_box[q]) prims.push_back((int)q); // a primitive without extent is never hit
+            if (prims.size() >= 2) {
+                AABB rootbox(Vec3(0, 0, 0), Vec3(0, 0, 0));
+                it.alt_first = build_alt_tree(prims, 0, prims.size(), 1, scale / 8192.0, &rootbox);
+            }
+        }
     } else if (auto list = dynamic_cast<const HittableList *>(h)) {
         it.kind = RTMI_ITEM_LIST;
         it.first = (int32_t)out.prim_meta.size();
@@ -810,6 +930,8 @@ rtmi_scene_desc LoweredScene::desc() const {
     d.n_images = (uint32_t)images.size(); d.images = images.data();
     d.image_data = image_data.data(); d.image_bytes = image_data.size();
     d.max_bvh_depth = max_bvh_depth;
+    d.prim_gate = prim_gate.data();
+    d.alt_max_depth = alt_max_depth;
     d.bvh_time_lo = bvh_time_lo; d.bvh_time_hi = bvh_time_hi;
     return d;
 }

@@ -325,6 +325,10 @@ struct LoweredScene {
     std::vector<rtmi_item> items;
     std::vector<float> prim_a, prim_b;
     std::vector<rtmi_prim_meta> prim_meta;
+    std::vector<float> prim_gate;  // 8 floats per primitive: box of its parent BVHNode in the reference tree (rtmi.h)
+    std::vector<AABB> prim_box;    // host only: true extent of a BVH primitive (its alternative tree is built on it)
+    std::vector<char> prim_has_box;
+    uint32_t alt_max_depth = 0;    // deepest alternative tree
     std::vector<rtmi_bvh_node> nodes;
     std::vector<rtmi_xform> xforms;
     std::vector<rtmi_material> materials;
@@ -352,6 +356,7 @@ class SceneBuilder {
     void lower_item(const Hittable &h);
     int push_prim(const Hittable &h, bool flip, bool force_moving);
     int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves);
+    int32_t build_alt_tree(std::vector<int> &prims, size_t lo, size_t hi, uint32_t depth, double pad, AABB *box_out);
     int run_item_ = -1; // index of the item that collects the current run of plain top-level primitives
     std::map<const Texture *, int> tex_ids_;
     std::map<const Material *, int> mat_ids_;

@@ -31,9 +31,10 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("flags", [0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL,
+@pytest.mark.parametrize("flags", [0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_REF_TREE,
+                                   abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL,
                                    abi.RTMI_FLAG_ASYNC, abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL],
-                         ids=["exact", "coop-fast", "perlane-fast", "async-exact", "async-fast"])
+                         ids=["exact", "coop-fast", "coop-fast-reftree", "perlane-fast", "async-exact", "async-fast"])
 @pytest.mark.parametrize("name,nx,ny,ns", CASES)
 def test_scene_matches_fp32_oracle(host, orc32, name, nx, ny, ns, flags):
     cam, world = scenes_extra.build(host, name, nx, ny, seed=1)
@@ -76,6 +77,7 @@ def test_fast_cull_equals_exact(host, name, nx, ny, ns):
     print(name, "exact %.1f ms" % a["stats"]["render_ms"], end="")
     for label, flags in (("perlane-fast", abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL),
                          ("coop-fast", abi.RTMI_FLAG_FAST_CULL),
+                         ("coop-fast-reftree", abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_REF_TREE),
                          ("async-fast", abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL)):
         b = sc.render(cam, nx, ny, ns, seed=42, flags=flags, sig=True)
         print(", %s %.1f ms" % (label, b["stats"]["render_ms"]), end="")

@@ -105,3 +105,38 @@ def test_unsupported_nesting_fails_loudly(host):
         host.lower(nested)  # instanced object as a BVH leaf
     with pytest.raises(Unsupported):
         host.lower(host.HittableList())  # empty world
+
+
+def test_lowering_alternative_trees_and_gates(host):
+    """Every prunable BVH gets a second (SAH) tree over the same primitives; every BVH primitive carries the box
+    of its parent node in the reference tree (the gate the cooperative kernel accepts leaves through)."""
+    _, world = scenes.build(host, "final_scene", 8, 8, seed=1)
+    sc = host.lower(world)
+    a, d = sc.arrays(), sc.desc()
+    items = a["items"]
+    assert items[0].alt_first > 0 and items[5].alt_first > 0 and items[1].alt_first == -1
+    nodes, meta = a["nodes"], a["prim_meta"]
+    gate = np.ctypeslib.as_array(d.prim_gate, shape=(d.n_prims, 8))
+
+    def leaves(root):
+        out, stack = [], [root]
+        while stack:
+            n = nodes[stack.pop()]
+            for ref in (n.left, n.right):
+                if ref < 0:
+                    out.append(ref & 0x0FFFFFFF)
+                else:
+                    stack.append(ref)
+        return out
+
+    for it in (items[0], items[5]):
+        ref, alt = leaves(it.first), leaves(it.alt_first)
+        assert sorted(set(ref)) == sorted(set(alt))          # same primitives
+        assert len(alt) == len(set(alt))                     # each once in the alternative tree
+    # gate of a reference leaf = the box stored for... its parent: contains the primitive's own (exact) box here
+    n0 = nodes[items[0].first]
+    for prim in leaves(items[0].first)[:50]:
+        g = gate[prim]
+        A, B = a["prim_a"][prim], a["prim_b"][prim]          # cube: min.xyz, max.x | max.y, max.z
+        assert (g[0:3] <= A[0:3]).all() and g[4] >= A[3] and g[5] >= B[0] and g[6] >= B[1]
+    assert d.alt_max_depth >= 9 and (n0.left != 0 or n0.right != 0)
