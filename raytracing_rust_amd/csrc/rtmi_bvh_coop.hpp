@@ -48,8 +48,10 @@ struct CoopWork {
     int spill_cap;  // its capacity in entries: 64 * (deepest tree + 2)
 };
 
-// All 64 lanes must call this together.
-template <bool PROF>
+// All 64 lanes must call this together.  EXT = false is the lean instantiation for scenes that need neither
+// alternative trees nor a stack beyond LDS (pool = the full bound 64 * (depth + 2), no gate, no spill code: the
+// extra code costs 2-3 % everywhere through register allocation); EXT = true has both.
+template <bool PROF, bool EXT>
 __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, bool gated, float scale, bool active, const RayF &R,
                                                float time, float q_min, float q_max, const CoopWork &cw,
                                                bool &have, float &t_out, int &pf_out, bool &overflow,
@@ -99,7 +101,10 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         const unsigned long long m_need = __ballot(needw);
         const int n_need = __popcll(m_need);
         if (top == 0 && n_need == 64) break;
-        if (top > cap - 64) break;
+        if (top > cap - 64) { // no room for 64 more pushes
+            if (!EXT) overflow = true; // cannot happen: the LDS pool is the depth-first bound itself
+            break;
+        }
         const int take = n_need < top ? n_need : top;
         if (needw) {
             const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
@@ -168,7 +173,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
                     aray = ray;
                 }
                 bool hit = prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf);
-                if (hit && gated) { // alternative tree: the reference reaches this leaf iff its parent's box passes
+                if (EXT && hit && gated) { // alternative tree: the reference reaches this leaf iff its parent's box passes
                     const float4 g0 = sc.gate[idx * 2], g1 = sc.gate[idx * 2 + 1];
                     hit = aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, W, wqmin, wqmax);
                 }
@@ -190,6 +195,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+        if (!EXT) break;
         if (top > cap - 64) { // no room for 64 pushes: the older half goes to global memory, order kept
             const int m = (top / 2) & ~63;
             if (gtop + m > cw.spill_cap) { overflow = true; break; } // cannot happen by the depth-first bound
@@ -229,7 +235,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
 }
 
 // geometry of one item for the whole wavefront: every lane calls it; `active` lanes own a query
-template <bool PROF>
+template <bool PROF, bool EXT>
 __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_item &I, bool use_alt, bool active, const RayF &r,
                                                 float time, float q_min, float q_max, const CoopWork &cw,
                                                 float &t_out, int &pf_out, bool &overflow, unsigned long long *prof,
@@ -239,8 +245,8 @@ __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_i
         const bool enter = active && aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
                                               I.root_max[2], r, q_min, q_max);
         bool have = false;
-        const bool alt = use_alt && I.alt_first >= 0;
-        coop_bvh_query<PROF>(sc, alt ? I.alt_first : I.first, alt, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow,
+        const bool alt = EXT && use_alt && I.alt_first >= 0;
+        coop_bvh_query<PROF, EXT>(sc, alt ? I.alt_first : I.first, alt, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow,
                              prof, slot);
         return have;
     }

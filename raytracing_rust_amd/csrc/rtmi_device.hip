@@ -56,6 +56,7 @@ struct rtmi_scene {
     unsigned int *status = nullptr; // device words: [0] cooperative-traversal pool overflows (must stay 0),
                                     // [1] unit counter of the persistent wavefronts
     int slots = 0;                  // CUs x 16: resident wavefronts the render kernels are launched with
+    bool has_alt = false;           // some BVH item carries an alternative tree
     rtmi_texel *texels = nullptr; // scratch for the blocking host API
     size_t texel_count = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -199,6 +200,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         return rc;
     }
     s->dev.nodes = nodes4;
+    for (uint32_t i = 0; i < d->n_items; i++)
+        if (d->items[i].kind == RTMI_ITEM_BVH && d->items[i].alt_first >= 0) s->has_alt = true;
     s->dev.n_items = d->n_items;
     if (hipMalloc(reinterpret_cast<void **>(&s->status), 2 * sizeof(unsigned int)) != hipSuccess ||
         hipMemset(s->status, 0, 2 * sizeof(unsigned int)) != hipSuccess) {
@@ -385,11 +388,14 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     // LDS part of the traversal stack: 512 entries cover the deepest stack ever seen on the reference scenes
     // (447); deeper stacks continue in global memory (64 * (depth + 2) entries per wavefront, the bound of the
     // depth-first order), so the LDS footprint (7.7 KB per wavefront) does not depend on the tree depth
-    P.coop_cap = 512u;
-    if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
-    P.use_alt = (s->dev.gate != nullptr && !(p->flags & RTMI_FLAG_REF_TREE)) ? 1u : 0u;
-    const uint32_t deepest = s->meta.alt_max_depth > s->meta.max_bvh_depth ? s->meta.alt_max_depth : s->meta.max_bvh_depth;
+    P.use_alt = (s->dev.gate != nullptr && s->has_alt && !(p->flags & RTMI_FLAG_REF_TREE)) ? 1u : 0u;
+    const uint32_t deepest = (P.use_alt && s->meta.alt_max_depth > s->meta.max_bvh_depth) ? s->meta.alt_max_depth : s->meta.max_bvh_depth;
     P.spill_cap = 64u * (deepest + 2u);
+    // the lean kernel (no gates, no spill code) serves scenes whose whole stack bound fits 768 LDS entries and
+    // that walk the reference trees; everything else takes the extended one with a 512-entry LDS part
+    const bool ext = P.use_alt || deepest > 10u || (p->flags & (1u << 11));
+    P.coop_cap = ext ? 512u : P.spill_cap;
+    if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
     if (coop) {
         const size_t spill_bytes = (size_t)s->slots * P.spill_cap * sizeof(uint2);
         if (spill_bytes > s->spill_bytes) {
@@ -415,20 +421,21 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     blocks_total += grid.x; chunks_total += P.nchunks;
     HIP_TRY(hipMemsetAsync(s->status + 1, 0, sizeof(unsigned int), stream));
 #define RTMI_LAUNCH(KERN, F, S, PR, LDS) hipLaunchKernelGGL((KERN<F, S, PR>), grid, block, LDS, stream, s->dev, C, P)
-#define RTMI_LAUNCH_COOP(S, PR, W)                                                                                       \
+#define RTMI_LAUNCH_COOP(S, PR, W, E)                                                                                    \
     do {                                                                                                                 \
         if (coop_lds > 48u * 1024u)                                                                                      \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi_render_coop<S, PR, W>),                     \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi_render_coop<S, PR, W, E>),                  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds));                     \
-        hipLaunchKernelGGL((rtmi_render_coop<S, PR, W>), grid, block, coop_lds, stream, s->dev, C, P);                   \
+        hipLaunchKernelGGL((rtmi_render_coop<S, PR, W, E>), grid, block, coop_lds, stream, s->dev, C, P);                \
     } while (0)
     if (coop) {
         const uint32_t wps = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
-        if (prof) RTMI_LAUNCH_COOP(false, true, 3);
-        else if (sigf) RTMI_LAUNCH_COOP(true, false, 4);
-        else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3);
-        else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5);
-        else RTMI_LAUNCH_COOP(false, false, 4);
+        if (prof) RTMI_LAUNCH_COOP(false, true, 3, true);
+        else if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true);
+        else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3, true);
+        else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5, true);
+        else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true);
+        else RTMI_LAUNCH_COOP(false, false, 4, false);
     } else if (!async) {
         if (prof) { if (fast) RTMI_LAUNCH(rtmi_render_kernel, true, false, true, 0); else RTMI_LAUNCH(rtmi_render_kernel, false, false, true, 0); }
         else if (fast && sigf) RTMI_LAUNCH(rtmi_render_kernel, true, true, false, 0);
