@@ -184,6 +184,9 @@ typedef struct {
 #define RTMI_FLAG_SYNC 8u      /* per-lane BVH traversal instead of the wave-cooperative one (exact mode always is) */
 #define RTMI_FLAG_ASYNC 16u    /* per-lane state-machine kernel (experimental, kept for comparison) */
 #define RTMI_FLAG_REF_TREE 64u /* cooperative kernel: walk the reference-topology tree, not the alternative one */
+/* Diagnostic knobs in the upper flag bits (results never depend on them): bits 8..10 = wavefronts per SIMD the
+ * cooperative kernel is compiled for (3 or 5; default 4); bit 11 = a 256-entry LDS part of the traversal stack,
+ * so that it spills to global memory all the time (tests/test_gpu_parity.py). */
 #define RTMI_FLAG_SKY 32u      /* opt-in extension, off by default: a ray that misses the world returns the gradient
                                 * the reference keeps commented out at src/color.rs:18-20 instead of black (:21) */
 typedef struct {
