@@ -34,6 +34,7 @@ pub struct FlatScene {
     /// optional: 8 floats per primitive (include/rtmi.h, prim_gate); empty = none
     pub prim_gate: Vec<f32>,
     pub alt_max_depth: u32,
+    pub alt_nodes: Vec<RtmiBvh4Node>,
     pub nodes: Vec<RtmiBvhNode>,
     pub xforms: Vec<RtmiXform>,
     pub materials: Vec<RtmiMaterial>,
@@ -61,6 +62,8 @@ impl FlatScene {
             prim_meta: self.prim_meta.as_ptr(),
             prim_gate: if self.prim_gate.is_empty() { std::ptr::null() } else { self.prim_gate.as_ptr() },
             alt_max_depth: self.alt_max_depth,
+            n_alt_nodes: self.alt_nodes.len() as u32,
+            alt_nodes: self.alt_nodes.as_ptr(),
             n_nodes: self.nodes.len() as u32,
             nodes: self.nodes.as_ptr(),
             n_xforms: self.xforms.len() as u32,

@@ -4,7 +4,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTMI_ABI_VERSION: u32 = 3;
+pub const RTMI_ABI_VERSION: u32 = 4;
 pub const RTMI_FLAG_FAST_CULL: u32 = 1;
 pub const RTMI_FLAG_PATH_SIG: u32 = 2;
 pub const RTMI_FLAG_PROFILE: u32 = 4;
@@ -73,6 +73,19 @@ pub struct RtmiBvhNode {
 
 #[repr(C)]
 #[derive(Clone, Copy)]
+pub struct RtmiBvh4Node {
+    pub minx: [f32; 4],
+    pub miny: [f32; 4],
+    pub minz: [f32; 4],
+    pub maxx: [f32; 4],
+    pub maxy: [f32; 4],
+    pub maxz: [f32; 4],
+    pub child: [i32; 4],
+    pub pad: [i32; 4],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
 pub struct RtmiXform {
     pub kind: i32,
     pub x: f32,
@@ -108,6 +121,8 @@ pub struct RtmiSceneDesc {
     pub prim_meta: *const RtmiPrimMeta,
     pub prim_gate: *const f32,
     pub alt_max_depth: u32,
+    pub n_alt_nodes: u32,
+    pub alt_nodes: *const RtmiBvh4Node,
     pub n_nodes: u32,
     pub nodes: *const RtmiBvhNode,
     pub n_xforms: u32,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 3u
+#define RTMI_ABI_VERSION 4u
 #define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
 #define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
 
@@ -102,6 +102,14 @@ typedef struct {
     int32_t left, right;
     int32_t pad[2]; /* reserved: ignored on input (the library's device copy keeps derived child references here) */
 } rtmi_bvh_node; /* 64 B */
+/* Node of an ALTERNATIVE tree (see prim_gate): four children, SoA boxes.  child: node index (into alt_nodes),
+ * RTMI_LEAF(type, prim), or RTMI_NO_CHILD with an empty box (min > max). */
+typedef struct {
+    float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+    int32_t child[4];
+    int32_t pad[4]; /* reserved: ignored on input */
+} rtmi_bvh4_node; /* 128 B */
+#define RTMI_NO_CHILD ((int32_t)0x7fffffff)
 #define RTMI_LEAF(type, prim) ((int32_t)(0x80000000u | ((uint32_t)(type) << 28) | (uint32_t)(prim)))
 
 /* ---- instance transforms: Traslate (src/traslate.rs), Rotate (src/rotate.rs) ---- */
@@ -130,7 +138,7 @@ typedef struct {
     float scale;             /* BVH: largest |coordinate| of the root box (fast-cull margins only); 1e30 = never prune
                               * (a BVH whose boxes do not contain their primitives, e.g. Rect::bounding_box of a
                               * YZ/ZX rect, rect.rs:71-75: pruned traversal then visits what BVHNode::hit visits) */
-    int32_t alt_first;       /* BVH: root of the alternative tree over the same primitives (see prim_gate), or -1 */
+    int32_t alt_first;       /* BVH: root (index into alt_nodes) of the alternative tree over the same primitives, or -1 */
 } rtmi_item; /* 64 B */
 
 typedef struct {
@@ -145,12 +153,14 @@ typedef struct {
      * {min.xyz, 0, max.xyz, 0}.  BVHNode::hit (bvh.rs:70-73) reaches a leaf iff every ancestor's box passes
      * AABB::hit with the query's (t_min, t_max); the slab test is monotone in the box, so that is equivalent
      * to the parent's box passing.  With this "gate" any conservative tree over the same primitives (an item's
-     * alt_first: a SAH tree on the primitives' true extents) returns the reference's result bit for bit:
+     * alt_first: a 4-wide SAH tree on the primitives' true extents, alt_nodes) returns the reference's result bit for bit:
      * accept a primitive iff its own test AND its gate pass, keep the minimum t, ties -> larger primitive
      * index (= rightmost leaf of the reference tree).  Used by the cooperative kernel; the exact and per-lane
      * kernels walk the reference tree (items' first). */
     const float *prim_gate;
     uint32_t alt_max_depth; /* deepest alternative tree (sizes the traversal stack's global part) */
+    uint32_t n_alt_nodes;
+    const rtmi_bvh4_node *alt_nodes;
     uint32_t n_nodes;
     const rtmi_bvh_node *nodes;
     uint32_t n_xforms;

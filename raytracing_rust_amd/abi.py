@@ -9,7 +9,7 @@ import os
 
 from . import build as _build
 
-RTMI_ABI_VERSION = 3
+RTMI_ABI_VERSION = 4
 RTMI_MAX_BVH_DEPTH = 24
 RTMI_TILE = 8
 RTMI_FLAG_FAST_CULL = 1
@@ -54,6 +54,11 @@ class BvhNode(C.Structure):
                 ("left", C.c_int32), ("right", C.c_int32), ("pad", C.c_int32 * 2)]
 
 
+class Bvh4Node(C.Structure):
+    _fields_ = [("minx", C.c_float * 4), ("miny", C.c_float * 4), ("minz", C.c_float * 4), ("maxx", C.c_float * 4),
+                ("maxy", C.c_float * 4), ("maxz", C.c_float * 4), ("child", C.c_int32 * 4), ("pad", C.c_int32 * 4)]
+
+
 class Xform(C.Structure):
     _fields_ = [("kind", C.c_int32), ("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
 
@@ -69,6 +74,7 @@ class SceneDesc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("n_items", C.c_uint32), ("items", C.POINTER(Item)),
                 ("n_prims", C.c_uint32), ("prim_a", C.POINTER(C.c_float)), ("prim_b", C.POINTER(C.c_float)),
                 ("prim_meta", C.POINTER(PrimMeta)), ("prim_gate", C.POINTER(C.c_float)), ("alt_max_depth", C.c_uint32),
+                ("n_alt_nodes", C.c_uint32), ("alt_nodes", C.POINTER(Bvh4Node)),
                 ("n_nodes", C.c_uint32), ("nodes", C.POINTER(BvhNode)),
                 ("n_xforms", C.c_uint32), ("xforms", C.POINTER(Xform)),
                 ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),

@@ -51,7 +51,10 @@ struct CoopWork {
 // All 64 lanes must call this together.  EXT = false is the lean instantiation for scenes that need neither
 // alternative trees nor a stack beyond LDS (pool = the full bound 64 * (depth + 2), no gate, no spill code: the
 // extra code costs 2-3 % everywhere through register allocation); EXT = true has both.
-template <bool PROF, bool EXT>
+// W4: `root` is a node of the 4-wide alternative tree (sc.nodes4, always gated); a visit tests four child boxes,
+// keeps the nearest surviving child and pushes up to three.  Half the chain length of a binary tree: the
+// traversals are bound by their longest chain, not by their work.
+template <bool PROF, bool EXT, bool W4>
 __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, bool gated, float scale, bool active, const RayF &R,
                                                float time, float q_min, float q_max, const CoopWork &cw,
                                                bool &have, float &t_out, int &pf_out, bool &overflow,
@@ -101,7 +104,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         const unsigned long long m_need = __ballot(needw);
         const int n_need = __popcll(m_need);
         if (top == 0 && n_need == 64) break;
-        if (top > cap - 64) { // no room for 64 more pushes
+        if (top > cap - (W4 ? 192 : 64)) { // no room for this round's pushes (one per worker, three in a 4-wide tree)
             if (!EXT) overflow = true; // cannot happen: the LDS pool is the depth-first bound itself
             break;
         }
@@ -121,6 +124,10 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         bool push = false;
         uint32_t push_ref = 0u;
         float push_t = 0.0f;
+        int npush = 0;                    // W4: up to three of the four children are published
+        bool wok[4] = {false, false, false, false};
+        uint32_t wch[4] = {0u, 0u, 0u, 0u};
+        float wtn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (cur != COOP_NONE) {
             if (ray != cray) { // switch ray context
                 const float4 c0 = ctx[ray * 3 + 0], c1 = ctx[ray * 3 + 1], c2 = ctx[ray * 3 + 2];
@@ -142,6 +149,34 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
             }
             if (tent > limit) {
                 cur = COOP_NONE;
+            } else if (W4 && !(cur & (1u << 25))) { // internal node of the 4-wide tree
+                // These boxes only cull (acceptance is the primitive's own test and its gate) and are padded beyond
+                // every primitive, so the slab test may take min/max instead of the reference's sign select: a ray
+                // lying exactly in a box plane (NaN from 0 * inf) cannot hit anything inside the padding anyway.
+                const float4 *n = sc.nodes4 + (size_t)cur * 8; // minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] child[4] -
+                const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5];
+                const float4 chf = n[6];
+                const float ax0[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ax1[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
+                const float ay0[4] = {mny.x, mny.y, mny.z, mny.w}, ay1[4] = {mxy.x, mxy.y, mxy.z, mxy.w};
+                const float az0[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, az1[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+                wch[0] = __float_as_uint(chf.x); wch[1] = __float_as_uint(chf.y); wch[2] = __float_as_uint(chf.z); wch[3] = __float_as_uint(chf.w);
+                int nearest = -1;
+                float tnear = RTMI_FLT_MAX;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float x0 = (ax0[c] - W.o.x) * W.inv_d.x, x1 = (ax1[c] - W.o.x) * W.inv_d.x;
+                    const float y0 = (ay0[c] - W.o.y) * W.inv_d.y, y1 = (ay1[c] - W.o.y) * W.inv_d.y;
+                    const float z0 = (az0[c] - W.o.z) * W.inv_d.z, z1 = (az1[c] - W.o.z) * W.inv_d.z;
+                    const float tn = fmaxf(fmaxf(fmaxf(wqmin, fminf(x0, x1)), fminf(y0, y1)), fminf(z0, z1));
+                    const float tf = fminf(fminf(fminf(wqmax, fmaxf(x0, x1)), fmaxf(y0, y1)), fmaxf(z0, z1));
+                    wtn[c] = tn;
+                    wok[c] = tf > tn && !(tn > limit) && wch[c] != COOP_NONE;
+                    if (wok[c] && tn < tnear) { nearest = c; tnear = tn; }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) wok[c] = wok[c] && c != nearest; // what is left gets published
+                npush = (int)wok[0] + (int)wok[1] + (int)wok[2] + (int)wok[3];
+                if (nearest >= 0) { cur = wch[nearest]; tent = tnear; } else cur = COOP_NONE;
             } else if (!(cur & (1u << 25))) { // internal node
                 const float4 *n = sc.nodes + (size_t)cur * 4;
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
@@ -185,19 +220,32 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
             }
         }
         // ---- publish the far children
+        if (W4) { // exclusive prefix sum of the per-worker counts (0..3) from two ballots
+            const unsigned long long b0 = __ballot((npush & 1) != 0), b1 = __ballot((npush & 2) != 0);
+            const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                               2 * (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+            int at = top + before;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (wok[c]) pool[at] = make_uint2(((uint32_t)ray << 26) | wch[c], __float_as_uint(wtn[c]));
+                at += (int)wok[c];
+            }
+            top += __popcll(b0) + 2 * __popcll(b1);
+        } else {
         const unsigned long long m_push = __ballot(push);
         if (push) {
             const int pos = top + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_push >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_push, 0u));
             pool[pos] = make_uint2(((uint32_t)ray << 26) | push_ref, __float_as_uint(push_t));
         }
         top += __popcll(m_push);
+        }
         if (PROF && lane == 0) atomicMax(&prof[2 * 18], (unsigned long long)top); // deepest pool seen (diagnostics)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
         if (!EXT) break;
-        if (top > cap - 64) { // no room for 64 pushes: the older half goes to global memory, order kept
-            const int m = (top / 2) & ~63;
+        if (top > cap - (W4 ? 192 : 64)) { // no room for the pushes: the older half goes to global memory, order kept
+            const int m = top - 64; // > 0 (top > cap - 192 >= 64): keep the newest 64, so the hot loop can go on
             if (gtop + m > cw.spill_cap) { overflow = true; break; } // cannot happen by the depth-first bound
             for (int i = lane; i < m; i += 64) cw.spill[gtop + i] = pool[i];
             const int rest = top - m;
@@ -235,7 +283,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
 }
 
 // geometry of one item for the whole wavefront: every lane calls it; `active` lanes own a query
-template <bool PROF, bool EXT>
+template <bool PROF, bool EXT, bool W4>
 __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_item &I, bool use_alt, bool active, const RayF &r,
                                                 float time, float q_min, float q_max, const CoopWork &cw,
                                                 float &t_out, int &pf_out, bool &overflow, unsigned long long *prof,
@@ -245,9 +293,9 @@ __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_i
         const bool enter = active && aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
                                               I.root_max[2], r, q_min, q_max);
         bool have = false;
-        const bool alt = EXT && use_alt && I.alt_first >= 0;
-        coop_bvh_query<PROF, EXT>(sc, alt ? I.alt_first : I.first, alt, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow,
-                             prof, slot);
+        const bool alt = EXT && W4 && use_alt && I.alt_first >= 0; // wave-uniform
+        if (alt) coop_bvh_query<PROF, EXT, W4>(sc, I.alt_first, true, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow, prof, slot);
+        else coop_bvh_query<PROF, EXT, false>(sc, I.first, false, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow, prof, slot);
         return have;
     }
     // HittableList::hit — hittable.rs:37-47

@@ -116,7 +116,7 @@ static int validate(const rtmi_scene_desc *d) {
                 return fail(RTMI_ERR_INVALID, "item primitive range out of bounds");
         } else if (it.kind == RTMI_ITEM_BVH) {
             if (it.first < 0 || (uint32_t)it.first >= d->n_nodes) return fail(RTMI_ERR_INVALID, "item BVH root out of range");
-            if (it.alt_first >= 0 && ((uint32_t)it.alt_first >= d->n_nodes || !d->prim_gate))
+            if (it.alt_first >= 0 && ((uint32_t)it.alt_first >= d->n_alt_nodes || !d->prim_gate || !d->alt_nodes))
                 return fail(RTMI_ERR_INVALID, "item alternative tree out of range or prim_gate missing");
         } else {
             return fail(RTMI_ERR_INVALID, "bad item kind");
@@ -188,6 +188,18 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         };
         for (rtmi_bvh_node &n : nodes) { n.pad[0] = enc(n.left); n.pad[1] = enc(n.right); }
         rc = upload(s, reinterpret_cast<const float4 *>(nodes.data()), (size_t)d->n_nodes * 4, &nodes4);
+        if (!rc && d->n_alt_nodes && d->alt_nodes) { // 4-wide alternative trees: children stored pool-encoded
+            std::vector<rtmi_bvh4_node> alt(d->alt_nodes, d->alt_nodes + d->n_alt_nodes);
+            for (rtmi_bvh4_node &n : alt)
+                for (int c = 0; c < 4; c++) {
+                    if (n.child[c] == RTMI_NO_CHILD) n.child[c] = (int32_t)0xffffffffu;
+                    else {
+                        if (n.child[c] >= 0 && (uint32_t)n.child[c] >= d->n_alt_nodes) rc = fail(RTMI_ERR_INVALID, "alternative tree child out of range");
+                        n.child[c] = enc(n.child[c]);
+                    }
+                }
+            if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(alt.data()), (size_t)d->n_alt_nodes * 8, &s->dev.nodes4);
+        }
     }
     if (!rc) rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms);
     if (!rc) rc = upload(s, d->materials, d->n_materials, &s->dev.mats);
@@ -380,7 +392,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     // (it implements the fast-cull semantics); RTMI_FLAG_SYNC = per-lane traversal; RTMI_FLAG_ASYNC =
     // per-lane state machine (kept for comparison)
     const bool async = (p->flags & RTMI_FLAG_ASYNC) != 0u;
-    const bool coop_ok = s->meta.n_prims < (1u << 22) && s->meta.n_nodes < (1u << 25);
+    const bool coop_ok = s->meta.n_prims < (1u << 22) && s->meta.n_nodes < (1u << 25) && s->meta.n_alt_nodes < (1u << 25);
     const bool coop = fast && !sync && !async && coop_ok;
     P.status = s->status;
     P.queue = s->status + 1;
@@ -391,6 +403,10 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     P.use_alt = (s->dev.gate != nullptr && s->has_alt && !(p->flags & RTMI_FLAG_REF_TREE)) ? 1u : 0u;
     const uint32_t deepest = (P.use_alt && s->meta.alt_max_depth > s->meta.max_bvh_depth) ? s->meta.alt_max_depth : s->meta.max_bvh_depth;
     P.spill_cap = 64u * (deepest + 2u);
+    if (P.use_alt) { // a 4-wide visit leaves up to three pending entries per level
+        const uint32_t wide = 64u * (3u * s->meta.alt_max_depth + 2u);
+        if (wide > P.spill_cap) P.spill_cap = wide;
+    }
     // the lean kernel (no gates, no spill code) serves scenes whose whole stack bound fits 768 LDS entries and
     // that walk the reference trees; everything else takes the extended one with a 512-entry LDS part
     const bool ext = P.use_alt || deepest > 10u || (p->flags & (1u << 11));

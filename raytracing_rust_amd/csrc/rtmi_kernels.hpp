@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                     float t;
                     int pf;
-                    if (geom_query_coop<PROF, EXT>(sc, I, P.use_alt != 0u, need, R, pa.rtime, P.t_min, closest, cw, t, pf, overflow, prof, slot)) {
+                    if (geom_query_coop<PROF, EXT, EXT>(sc, I, P.use_alt != 0u, need, R, pa.rtime, P.t_min, closest, cw, t, pf, overflow, prof, slot)) {
                         closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                     }
                     prof_time<PROF>(prof, I.kind == RTMI_ITEM_BVH ? (it == 0 ? 27 : 28) : 26, tstamp);
@@ -218,8 +218,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         h1 = false; h2 = false;
                         if (need) sphere_two_queries(R, sc.prim_a[I.first], h1, t1, h2, t2);
                     } else {
-                        h1 = geom_query_coop<PROF, EXT>(sc, I, P.use_alt != 0u, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
-                        h2 = geom_query_coop<PROF, EXT>(sc, I, P.use_alt != 0u, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
+                        h1 = geom_query_coop<PROF, EXT, false>(sc, I, P.use_alt != 0u, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
+                        h2 = geom_query_coop<PROF, EXT, false>(sc, I, P.use_alt != 0u, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
                     }
                     if (need && h1 && h2) {
                         if (medium_sample(t1, t2, P.t_min, closest, W.d, I.neg_inv_density, g, k0, k1, tm)) {

@@ -40,6 +40,7 @@ struct DevScene {
     const rtmi_prim_meta *meta;
     const float4 *gate;  // 2 x float4 per primitive: box of its parent BVHNode in the reference tree (or NULL)
     const float4 *nodes; // 4 x float4 per rtmi_bvh_node
+    const float4 *nodes4; // 8 x float4 per rtmi_bvh4_node (alternative trees)
     const rtmi_xform *xforms;
     const rtmi_material *mats;
     const rtmi_texture *texs;

@@ -736,7 +736,6 @@ int32_t SceneBuilder::build_alt_tree(std::vector<int> &prims, size_t lo, size_t 
         *box_out = AABB(b.min - pd, b.max + pd);
         return RTMI_LEAF(out.prim_meta[(size_t)prim].type, prim);
     }
-    if (depth > out.alt_max_depth) out.alt_max_depth = depth;
     auto centroid = [&](int p, int a) { const AABB &b = out.prim_box[(size_t)p]; return 0.5 * (b.min[a] + b.max[a]); };
     size_t mid = lo + n / 2;
     bool split_done = false;
@@ -798,16 +797,59 @@ int32_t SceneBuilder::build_alt_tree(std::vector<int> &prims, size_t lo, size_t 
         mid = lo + n / 2;
         std::stable_sort(prims.begin() + (long)lo, prims.begin() + (long)hi, [&](int a, int b) { return centroid(a, axis) < centroid(b, axis); });
     }
-    const int32_t id = (int32_t)out.nodes.size();
-    out.nodes.push_back(rtmi_bvh_node{});
+    const int32_t id = (int32_t)alt_scratch_.size();
+    alt_scratch_.push_back(rtmi_bvh_node{});
     AABB lb, rb;
     const int32_t l = build_alt_tree(prims, lo, mid, depth + 1, pad, &lb);
     const int32_t r = build_alt_tree(prims, mid, hi, depth + 1, pad, &rb);
-    rtmi_bvh_node &me = out.nodes[(size_t)id];
+    rtmi_bvh_node &me = alt_scratch_[(size_t)id];
     put_box(me.lmin, me.lmax, lb);
     put_box(me.rmin, me.rmax, rb);
     me.left = l; me.right = r;
     *box_out = surrounding_box(lb, rb);
+    return id;
+}
+
+// Binary SAH tree (alt_scratch_) -> 4-wide nodes: a node's children are its grandchildren where the child is an
+// internal node, the child itself where it is a leaf.  Returns a child reference for the 4-wide tree.
+int32_t SceneBuilder::collapse_alt(int32_t ref, uint32_t depth) {
+    if (ref < 0) return ref; // leaf
+    if (depth > out.alt_max_depth) out.alt_max_depth = depth;
+    const int32_t id = (int32_t)out.alt_nodes.size();
+    out.alt_nodes.push_back(rtmi_bvh4_node{});
+    struct Slot { int32_t ref; float mn[3], mx[3]; };
+    std::vector<Slot> slots;
+    const rtmi_bvh_node b = alt_scratch_[(size_t)ref];
+    auto add = [&](int32_t r, const float *mn, const float *mx) {
+        Slot sl; sl.ref = r;
+        for (int k = 0; k < 3; k++) { sl.mn[k] = mn[k]; sl.mx[k] = mx[k]; }
+        slots.push_back(sl);
+    };
+    const int32_t ch[2] = {b.left, b.right};
+    const float *cmn[2] = {b.lmin, b.rmin}, *cmx[2] = {b.lmax, b.rmax};
+    for (int c = 0; c < 2; c++) {
+        if (ch[c] >= 0) {
+            const rtmi_bvh_node g = alt_scratch_[(size_t)ch[c]];
+            add(g.left, g.lmin, g.lmax);
+            add(g.right, g.rmin, g.rmax);
+        } else {
+            add(ch[c], cmn[c], cmx[c]);
+        }
+    }
+    rtmi_bvh4_node me{};
+    const float big = 3.40282346638528859811704183484516925e+38f;
+    for (int c = 0; c < 4; c++) {
+        if (c < (int)slots.size()) {
+            me.minx[c] = slots[c].mn[0]; me.miny[c] = slots[c].mn[1]; me.minz[c] = slots[c].mn[2];
+            me.maxx[c] = slots[c].mx[0]; me.maxy[c] = slots[c].mx[1]; me.maxz[c] = slots[c].mx[2];
+            me.child[c] = collapse_alt(slots[c].ref, depth + 1);
+        } else { // empty slot: a box no ray can hit
+            me.minx[c] = me.miny[c] = me.minz[c] = big;
+            me.maxx[c] = me.maxy[c] = me.maxz[c] = -big;
+            me.child[c] = RTMI_NO_CHILD;
+        }
+    }
+    out.alt_nodes[(size_t)id] = me;
     return id;
 }
 
@@ -864,7 +906,9 @@ void SceneBuilder::lower_item(const Hittable &top) {
                 if (out.prim_has_box[q]) prims.push_back((int)q); // a primitive without extent is never hit
             if (prims.size() >= 2) {
                 AABB rootbox(Vec3(0, 0, 0), Vec3(0, 0, 0));
-                it.alt_first = build_alt_tree(prims, 0, prims.size(), 1, scale / 8192.0, &rootbox);
+                alt_scratch_.clear();
+                const int32_t broot = build_alt_tree(prims, 0, prims.size(), 1, scale / 8192.0, &rootbox);
+                it.alt_first = collapse_alt(broot, 1);
             }
         }
     } else if (auto list = dynamic_cast<const HittableList *>(h)) {
@@ -932,6 +976,7 @@ rtmi_scene_desc LoweredScene::desc() const {
     d.max_bvh_depth = max_bvh_depth;
     d.prim_gate = prim_gate.data();
     d.alt_max_depth = alt_max_depth;
+    d.n_alt_nodes = (uint32_t)alt_nodes.size(); d.alt_nodes = alt_nodes.data();
     d.bvh_time_lo = bvh_time_lo; d.bvh_time_hi = bvh_time_hi;
     return d;
 }

@@ -328,7 +328,8 @@ struct LoweredScene {
     std::vector<float> prim_gate;  // 8 floats per primitive: box of its parent BVHNode in the reference tree (rtmi.h)
     std::vector<AABB> prim_box;    // host only: true extent of a BVH primitive (its alternative tree is built on it)
     std::vector<char> prim_has_box;
-    uint32_t alt_max_depth = 0;    // deepest alternative tree
+    uint32_t alt_max_depth = 0;    // deepest alternative tree (in 4-wide nodes)
+    std::vector<rtmi_bvh4_node> alt_nodes; // the alternative trees
     std::vector<rtmi_bvh_node> nodes;
     std::vector<rtmi_xform> xforms;
     std::vector<rtmi_material> materials;
@@ -357,6 +358,8 @@ class SceneBuilder {
     int push_prim(const Hittable &h, bool flip, bool force_moving);
     int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves);
     int32_t build_alt_tree(std::vector<int> &prims, size_t lo, size_t hi, uint32_t depth, double pad, AABB *box_out);
+    int32_t collapse_alt(int32_t ref, uint32_t depth); // binary scratch tree -> 4-wide nodes in out.alt_nodes
+    std::vector<rtmi_bvh_node> alt_scratch_;            // binary SAH tree being built for the current item
     int run_item_ = -1; // index of the item that collects the current run of plain top-level primitives
     std::map<const Texture *, int> tex_ids_;
     std::map<const Material *, int> mat_ids_;

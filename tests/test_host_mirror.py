@@ -108,17 +108,19 @@ def test_unsupported_nesting_fails_loudly(host):
 
 
 def test_lowering_alternative_trees_and_gates(host):
-    """Every prunable BVH gets a second (SAH) tree over the same primitives; every BVH primitive carries the box
-    of its parent node in the reference tree (the gate the cooperative kernel accepts leaves through)."""
+    """Every prunable BVH gets a second, 4-wide SAH tree over the same primitives; every BVH primitive carries the
+    box of its parent node in the reference tree (the gate the cooperative kernel accepts leaves through)."""
     _, world = scenes.build(host, "final_scene", 8, 8, seed=1)
     sc = host.lower(world)
     a, d = sc.arrays(), sc.desc()
     items = a["items"]
-    assert items[0].alt_first > 0 and items[5].alt_first > 0 and items[1].alt_first == -1
-    nodes, meta = a["nodes"], a["prim_meta"]
+    assert items[0].alt_first >= 0 and items[5].alt_first > 0 and items[1].alt_first == -1
+    nodes = a["nodes"]
+    alt = [d.alt_nodes[i] for i in range(d.n_alt_nodes)]
     gate = np.ctypeslib.as_array(d.prim_gate, shape=(d.n_prims, 8))
+    NO_CHILD = 0x7FFFFFFF
 
-    def leaves(root):
+    def ref_leaves(root):
         out, stack = [], [root]
         while stack:
             n = nodes[stack.pop()]
@@ -129,14 +131,33 @@ def test_lowering_alternative_trees_and_gates(host):
                     stack.append(ref)
         return out
 
+    def alt_leaves(root):
+        out, stack, depth = [], [(root, 1)], 0
+        while stack:
+            i, dp = stack.pop()
+            depth = max(depth, dp)
+            n = alt[i]
+            for c in range(4):
+                ref = n.child[c]
+                if ref == NO_CHILD:
+                    assert n.minx[c] > n.maxx[c]                      # an empty slot cannot be hit
+                elif ref < 0:
+                    prim = ref & 0x0FFFFFFF
+                    out.append(prim)
+                    A, B = a["prim_a"][prim], a["prim_b"][prim]      # cube: min.xyz, max.x | max.y, max.z
+                    if a["prim_meta"][prim].type == abi.PRIM_CUBE:  # the padded leaf box contains the primitive
+                        assert n.minx[c] <= A[0] and n.miny[c] <= A[1] and n.minz[c] <= A[2]
+                        assert n.maxx[c] >= A[3] and n.maxy[c] >= B[0] and n.maxz[c] >= B[1]
+                else:
+                    stack.append((ref, dp + 1))
+        return out, depth
+
     for it in (items[0], items[5]):
-        ref, alt = leaves(it.first), leaves(it.alt_first)
-        assert sorted(set(ref)) == sorted(set(alt))          # same primitives
-        assert len(alt) == len(set(alt))                     # each once in the alternative tree
-    # gate of a reference leaf = the box stored for... its parent: contains the primitive's own (exact) box here
-    n0 = nodes[items[0].first]
-    for prim in leaves(items[0].first)[:50]:
+        ref = ref_leaves(it.first)
+        al, depth = alt_leaves(it.alt_first)
+        assert sorted(set(ref)) == sorted(al)                        # same primitives, each once
+        assert depth <= d.alt_max_depth <= 8                          # 4-wide: about half the binary depth
+    for prim in ref_leaves(items[0].first)[:50]:                     # gate = parent box: contains the cube
         g = gate[prim]
-        A, B = a["prim_a"][prim], a["prim_b"][prim]          # cube: min.xyz, max.x | max.y, max.z
+        A, B = a["prim_a"][prim], a["prim_b"][prim]
         assert (g[0:3] <= A[0:3]).all() and g[4] >= A[3] and g[5] >= B[0] and g[6] >= B[1]
-    assert d.alt_max_depth >= 9 and (n0.left != 0 or n0.right != 0)

@@ -11,7 +11,7 @@ from raytracing_rust_amd import abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SYS = open(os.path.join(ROOT, "bindings", "rust", "src", "sys.rs")).read()
 PAIRS = {"RtmiTexture": abi.Texture, "RtmiPerlin": abi.Perlin, "RtmiImage": abi.ImageDesc, "RtmiMaterial": abi.Material,
-         "RtmiPrimMeta": abi.PrimMeta, "RtmiBvhNode": abi.BvhNode, "RtmiXform": abi.Xform, "RtmiItem": abi.Item,
+         "RtmiPrimMeta": abi.PrimMeta, "RtmiBvhNode": abi.BvhNode, "RtmiBvh4Node": abi.Bvh4Node, "RtmiXform": abi.Xform, "RtmiItem": abi.Item,
          "RtmiSceneDesc": abi.SceneDesc, "RtmiCamera": abi.Camera, "RtmiRenderParams": abi.RenderParams,
          "RtmiTexel": abi.Texel, "RtmiStats": abi.Stats}
 SCALAR = {"i32": 4, "u32": 4, "f32": 4, "u64": 8, "f64": 8, "u8": 1}
