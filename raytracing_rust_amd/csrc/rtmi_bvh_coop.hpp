@@ -125,7 +125,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         uint32_t push_ref = 0u;
         float push_t = 0.0f;
         int npush = 0;                    // W4: up to three of the four children are published
-        bool wok[4] = {false, false, false, false};
+        uint32_t wkeep = 0u;              // bit c: child c is published
         uint32_t wch[4] = {0u, 0u, 0u, 0u};
         float wtn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (cur != COOP_NONE) {
@@ -170,13 +170,12 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
                     const float tn = fmaxf(fmaxf(fmaxf(wqmin, fminf(x0, x1)), fminf(y0, y1)), fminf(z0, z1));
                     const float tf = fminf(fminf(fminf(wqmax, fmaxf(x0, x1)), fmaxf(y0, y1)), fmaxf(z0, z1));
                     wtn[c] = tn;
-                    wok[c] = tf > tn && !(tn > limit) && wch[c] != COOP_NONE;
-                    if (wok[c] && tn < tnear) { nearest = c; tnear = tn; }
+                    const bool okc = tf > tn && !(tn > limit) && wch[c] != COOP_NONE;
+                    if (okc) wkeep |= 1u << c;
+                    if (okc && tn < tnear) { nearest = c; tnear = tn; }
                 }
-#pragma unroll
-                for (int c = 0; c < 4; c++) wok[c] = wok[c] && c != nearest; // what is left gets published
-                npush = (int)wok[0] + (int)wok[1] + (int)wok[2] + (int)wok[3];
-                if (nearest >= 0) { cur = wch[nearest]; tent = tnear; } else cur = COOP_NONE;
+                if (nearest >= 0) { cur = wch[nearest]; tent = tnear; wkeep &= ~(1u << nearest); } else cur = COOP_NONE;
+                npush = __popc(wkeep); // what is left gets published
             } else if (!(cur & (1u << 25))) { // internal node
                 const float4 *n = sc.nodes + (size_t)cur * 4;
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
@@ -227,8 +226,8 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
             int at = top + before;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                if (wok[c]) pool[at] = make_uint2(((uint32_t)ray << 26) | wch[c], __float_as_uint(wtn[c]));
-                at += (int)wok[c];
+                if (wkeep & (1u << c)) pool[at] = make_uint2(((uint32_t)ray << 26) | wch[c], __float_as_uint(wtn[c]));
+                at += (int)((wkeep >> c) & 1u);
             }
             top += __popcll(b0) + 2 * __popcll(b1);
         } else {
