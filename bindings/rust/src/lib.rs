@@ -124,6 +124,8 @@ pub fn default_params(nx: usize, ny: usize, ns: usize, seed: u64) -> RtmiRenderP
         path_sig: 0,
         prof: 0,
         sample_buffer_bytes: 0,
+        progress_fn: 0,
+        progress_user: 0,
     }
 }
 

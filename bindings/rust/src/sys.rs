@@ -4,7 +4,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTMI_ABI_VERSION: u32 = 4;
+pub const RTMI_ABI_VERSION: u32 = 5;
 pub const RTMI_FLAG_FAST_CULL: u32 = 1;
 pub const RTMI_FLAG_PATH_SIG: u32 = 2;
 pub const RTMI_FLAG_PROFILE: u32 = 4;
@@ -12,6 +12,15 @@ pub const RTMI_FLAG_SYNC: u32 = 8;
 pub const RTMI_FLAG_ASYNC: u32 = 16;
 pub const RTMI_FLAG_SKY: u32 = 32;
 pub const RTMI_FLAG_REF_TREE: u32 = 64;
+pub const RTMI_FLAG_FACE_FORWARD: u32 = 128;
+pub const RTMI_FLAG_UV_BOOK: u32 = 4096;
+pub const RTMI_OK: i32 = 0;
+pub const RTMI_ERR_INVALID: i32 = 1;
+pub const RTMI_ERR_UNSUPPORTED: i32 = 2;
+pub const RTMI_ERR_DEVICE: i32 = 3;
+pub const RTMI_ERR_NOMEM: i32 = 4;
+pub const RTMI_ERR_CANCELLED: i32 = 5;
+pub const RTMI_TEXEL_POISON: u32 = 0x8000_0000;
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -173,7 +182,12 @@ pub struct RtmiRenderParams {
     pub path_sig: u64,
     pub prof: u64,
     pub sample_buffer_bytes: u64,
+    /// `RtmiProgressFn` cast to an integer, or 0 (called by the blocking entry points about every 50 ms)
+    pub progress_fn: u64,
+    pub progress_user: u64,
 }
+/// `int (*)(uint64_t done, uint64_t total, void *user)`; non-zero return = cancel (RTMI_ERR_CANCELLED)
+pub type RtmiProgressFn = unsafe extern "C" fn(done: u64, total: u64, user: *mut c_void) -> c_int;
 
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -214,6 +228,17 @@ extern "C" {
         p: *const RtmiRenderParams,
         d_texels: *mut c_void,
         stream: *mut c_void,
+        stats: *mut RtmiStats,
+    ) -> c_int;
+    pub fn rtmi_scene_status(scene: *mut RtmiScene, overflows: *mut u32) -> c_int;
+    pub fn rtmi_render_multi(
+        desc: *const RtmiSceneDesc,
+        devices: *const c_int,
+        n_devices: u32,
+        cam: *const RtmiCamera,
+        p: *const RtmiRenderParams,
+        out_linear_rgb: *mut f32,
+        out_rgb8: *mut u8,
         stats: *mut RtmiStats,
     ) -> c_int;
     pub fn rtmi_render(

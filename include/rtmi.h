@@ -30,11 +30,11 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 4u
+#define RTMI_ABI_VERSION 5u
 #define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
 #define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
 
-enum { RTMI_OK = 0, RTMI_ERR_INVALID = 1, RTMI_ERR_UNSUPPORTED = 2, RTMI_ERR_DEVICE = 3, RTMI_ERR_NOMEM = 4 };
+enum { RTMI_OK = 0, RTMI_ERR_INVALID = 1, RTMI_ERR_UNSUPPORTED = 2, RTMI_ERR_DEVICE = 3, RTMI_ERR_NOMEM = 4, RTMI_ERR_CANCELLED = 5 };
 
 /* ---- textures: Texture::value (src/texture.rs) -------------------------------- */
 enum { RTMI_TEX_SOLID = 0, RTMI_TEX_CHECKER = 1, RTMI_TEX_NOISE = 2, RTMI_TEX_IMAGE = 3 };
@@ -199,6 +199,16 @@ typedef struct {
  * so that it spills to global memory all the time (tests/test_gpu_parity.py). */
 #define RTMI_FLAG_SKY 32u      /* opt-in extension, off by default: a ray that misses the world returns the gradient
                                 * the reference keeps commented out at src/color.rs:18-20 instead of black (:21) */
+/* Two more opt-in extensions, off by default; the default path reproduces the reference's quirks. */
+#define RTMI_FLAG_FACE_FORWARD 128u /* Lambertian / Metal / Isotropic scatter and Metal's absorption test use the
+                                * normal turned against the incoming ray (n := -n when d.n > 0).  The reference never
+                                * turns it (src/sphere.rs:50 outward, src/rect.rs:58-59 always +e_k), so e.g. the three
+                                * min-side faces of a Cube (src/cube.rs:21-74) scatter into the box.  Dielectric keeps
+                                * the geometric normal: it resolves the side itself (src/material.rs:106-114). */
+#define RTMI_FLAG_UV_BOOK 4096u /* get_sphere_uv with v = (theta + pi/2) / pi (the book's formula) instead of the
+                                * reference's FRAC_2_PI = 2/pi (src/sphere.rs:13), i.e. v in [0,1] */
+#define RTMI_FLAG_TEST_OVERFLOW 8192u /* test knob: the cooperative kernel reports a traversal-pool overflow although
+                                * none happened, to exercise the error path (results of that call are poisoned) */
 typedef struct {
     uint32_t nx, ny, ns; /* create_image(ny, nx, ns, ..) */
     uint32_t max_depth;  /* 50 (color.rs:9) */
@@ -213,7 +223,15 @@ typedef struct {
     uint64_t sample_buffer_bytes;   /* budget of the per-sample radiance buffer (16 B per pixel sample of this rank);
                                      * 0 = default (all ns samples when they fit 48 GiB and 3/4 of the free HBM);
                                      * a smaller budget renders the sample range in passes — same result */
+    /* Progress callback (replaces the reference's stand-alone bar, src/progressbar.rs:6-58, which only sleeps): the
+     * blocking entry points (rtmi_render, rtmi_render_multi) call it from the calling thread about every 50 ms while
+     * the kernels run, and once with done == total at the end.  `done`/`total` count work units (8x8 tile x sample
+     * chunk) handed out by the device's unit queue.  A non-zero return value is remembered and the call returns
+     * RTMI_ERR_CANCELLED after the running launch (launches are not pre-empted).  0 = no callback. */
+    uint64_t progress_fn;           /* rtmi_progress_fn cast to an integer, or 0 */
+    uint64_t progress_user;         /* passed back as `user` */
 } rtmi_render_params;
+typedef int (*rtmi_progress_fn)(uint64_t done, uint64_t total, void *user);
 
 /* Path signature (test/validation aid): for every hit query of every sample that finds a hit,
  * mix(bits of the fp32 hit distance t, bounce index) is added (wrapping uint64) to the pixel's
@@ -222,7 +240,9 @@ typedef struct {
  *   mix(x,k): x ^= (k+1)*0x9E3779B9; x ^= x>>16; x *= 0x7FEB352D; x ^= x>>15; x *= 0x846CA68B; x ^= x>>16 */
 
 /* One framebuffer texel: mean linear radiance (before gamma) and the quantised
- * ir,ig,ib of tests/test.rs:71-78 packed as r | g<<8 | b<<16. */
+ * ir,ig,ib of tests/test.rs:71-78 packed as r | g<<8 | b<<16.  Bit 31 of rgb8 (RTMI_TEXEL_POISON) marks a texel of
+ * a launch whose cooperative traversal pool overflowed (results invalid; r,g,b are NaN): rtmi_untile refuses it. */
+#define RTMI_TEXEL_POISON 0x80000000u
 typedef struct {
     float r, g, b;
     uint32_t rgb8;
@@ -256,9 +276,27 @@ int rtmi_render_prepare(rtmi_scene *scene, const rtmi_render_params *params);
 
 /* Enqueues the render on `stream` (a hipStream_t, may be NULL) and writes
  * rtmi_local_tiles()*64 texels to the DEVICE buffer d_texels.  Does not synchronise
- * unless `stats` is non-NULL (then it waits for the kernels to fill kernel_ms). */
+ * unless `stats` is non-NULL (then it waits for the kernels to fill kernel_ms, and reports a traversal-pool
+ * overflow as RTMI_ERR_DEVICE).  Without `stats` the call is asynchronous: an overflow poisons the texels of
+ * that launch (RTMI_TEXEL_POISON) and is reported by the next rtmi_scene_status(). */
 int rtmi_render_device(rtmi_scene *scene, const rtmi_camera *cam, const rtmi_render_params *p, void *d_texels,
                        void *stream, rtmi_stats *stats);
+
+/* Waits for the scene's device and returns RTMI_ERR_DEVICE if any render launch since the last call (or since
+ * a render call that reported it) overflowed its cooperative traversal pool; the condition is cleared by the
+ * report.  *overflows (optional) receives the number of wavefronts that saw one.  Cannot happen by the
+ * depth-first bound of the pool; this is the loud end of that argument for the asynchronous entry point. */
+int rtmi_scene_status(rtmi_scene *scene, uint32_t *overflows);
+
+/* Whole image on several GPUs of this process: the scene description is uploaded to every
+ * listed device, device i renders the tiles t with t % n_devices == i on its own stream (all devices run
+ * concurrently), the tile-packed framebuffers are gathered on devices[0] — one ncclGather over xGMI
+ * (rccl.h ncclGather) when the listed devices are distinct, plain device-to-device copies when a device is
+ * listed more than once (single-GPU rehearsal: RCCL cannot put two ranks on one device) — and un-tiled into the
+ * host buffers exactly like rtmi_render.  The image is bit-identical to rtmi_render's for any device list.
+ * stats (optional): kernel_ms / render_ms = the slowest device's, samples = all devices'. */
+int rtmi_render_multi(const rtmi_scene_desc *desc, const int *devices, uint32_t n_devices, const rtmi_camera *cam,
+                      const rtmi_render_params *p, float *out_linear_rgb, uint8_t *out_rgb8, rtmi_stats *stats);
 
 /* Blocking whole-image render into host buffers (tile_world must be 1):
  * out_linear_rgb: ny*nx*3 floats, row 0 = top row (reference j = ny-1); may be NULL

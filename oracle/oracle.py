@@ -19,6 +19,8 @@ _BUILD = os.path.join(_HERE, "_build")
 ARITH_DEVICE = 1
 THROUGHPUT_FORM = 2
 SKY = 4  # opt-in extension: gradient background of color.rs:18-20 (commented out in the reference)
+FACE_FORWARD = 8  # opt-in extension: opaque materials scatter about the normal turned against the ray
+UV_BOOK = 16  # opt-in extension: get_sphere_uv with pi/2 (the book) instead of FRAC_2_PI (sphere.rs:13)
 
 COUNTER_NAMES = [
     "samples", "queries", "aabb", "sphere", "msphere", "rect", "xform", "medium", "medium_draw",
@@ -36,9 +38,23 @@ def build():
     subprocess.run(["make", "-C", _HERE, "all"], check=True, stdout=subprocess.DEVNULL)
 
 
+_NATIVE_BUILT = False
+
+
+def build_native():
+    """The timed CPU-baseline library: no counters, -march=native.  Rebuilt once per process tree on the host
+    that runs it (the file may have been compiled on another host); forked workers inherit the flag."""
+    global _NATIVE_BUILT
+    if not _NATIVE_BUILT:
+        subprocess.run(["make", "-B", "-C", _HERE, "native"], check=True, stdout=subprocess.DEVNULL)
+        _NATIVE_BUILT = True
+
+
 def _load(name):
     path = os.path.join(_BUILD, name)
-    if not os.path.exists(path):
+    if name == "liborc_f64_native.so":
+        build_native()
+    elif not os.path.exists(path):
         build()
     lib = C.CDLL(path)
     vp, d, i, u64 = C.c_void_p, C.c_double, C.c_int, C.c_uint64
@@ -123,10 +139,12 @@ class Oracle:
     PLANE_YZ, PLANE_ZX, PLANE_XY = PLANE_YZ, PLANE_ZX, PLANE_XY
     AXIS_X, AXIS_Y, AXIS_Z = AXIS_X, AXIS_Y, AXIS_Z
 
-    def __init__(self, precision="f64"):
+    def __init__(self, precision="f64", native=False):
+        """native=True: the uninstrumented -march=native f64 build that bench.py times as the CPU baseline."""
         assert precision in ("f64", "f32")
+        assert not native or precision == "f64"
         self.precision = precision
-        self.lib = _load("liborc_%s.so" % precision)
+        self.lib = _load("liborc_f64_native.so" if native else "liborc_%s.so" % precision)
         assert self.lib.orc_is_f32() == (1 if precision == "f32" else 0)
 
     # ---- scene RNG (the reference's thread_rng during construction) ----

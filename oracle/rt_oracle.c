@@ -64,8 +64,13 @@ typedef double REAL;
 enum {
     ORC_ARITH_DEVICE = 1,  /* fp32 arithmetic contract substitutions      */
     ORC_THROUGHPUT_FORM = 2, /* iterative L += T*e form of color() instead of the recursion */
-    ORC_SKY = 4              /* opt-in extension: the gradient background the reference keeps
+    ORC_SKY = 4,             /* opt-in extension: the gradient background the reference keeps
                               * commented out at color.rs:18-20 (default: black, color.rs:21)  */
+    ORC_FACE_FORWARD = 8,    /* opt-in extension: Lambertian / Metal / Isotropic scatter about the normal turned
+                              * against the incoming ray (the reference never turns it: sphere.rs:50, rect.rs:58-59);
+                              * Dielectric keeps the geometric normal (material.rs:106-114)                      */
+    ORC_UV_BOOK = 16         /* opt-in extension: get_sphere_uv adds pi/2 (the book) instead of FRAC_2_PI
+                              * (sphere.rs:13)                                                                  */
 };
 static int g_flags = 0;
 #define DEVICE_ARITH (g_flags & ORC_ARITH_DEVICE)
@@ -79,7 +84,11 @@ enum {
     C_RECT_ACCEPT, C_NCOUNTERS
 };
 static uint64_t g_cnt[C_NCOUNTERS];
+#ifdef ORC_NO_COUNT /* the timed CPU-baseline build: no instrumentation on the hot path */
+#define COUNT(k) ((void)0)
+#else
 #define COUNT(k) (g_cnt[k]++)
+#endif
 
 /* ---- Philox4x32-10 (Salmon et al., SC'11) ------------------------------------- */
 static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
@@ -431,6 +440,12 @@ static V3 mat_emitted(const Material *m, REAL u, REAL v, V3 p) {
 /* Material::scatter — material.rs:31 and impls */
 static int mat_scatter(const Material *m, const Ray *ray, const HitRecord *hit, Ray *scattered, V3 *attenuation) {
     COUNT(C_MAT_FETCH);
+    HitRecord turned;
+    if ((g_flags & ORC_FACE_FORWARD) && m->kind != MAT_DIELECTRIC && v_dot(ray->d, hit->normal) > (REAL)0.0) {
+        turned = *hit;
+        turned.normal = v3(-hit->normal.x, -hit->normal.y, -hit->normal.z);
+        hit = &turned;
+    }
     switch (m->kind) {
     case MAT_LAMBERTIAN: { /* material.rs:49-53 */
         COUNT(C_SC_LAMBERT);
@@ -526,7 +541,12 @@ static void get_sphere_uv(V3 p, REAL *u, REAL *v) {
     const REAL PI = 3.14159265358979323846264338327950288, FRAC_2_PI = 0.636619772367581343075535053490057448;
 #endif
     *u = (REAL)1.0 - (phi + PI) / ((REAL)2.0 * PI);
-    *v = (theta + FRAC_2_PI) / PI; /* sic: FRAC_2_PI, not FRAC_PI_2 */
+#ifdef ORC_F32
+    const REAL FRAC_PI_2 = RTMI_PIO2_F;
+#else
+    const REAL FRAC_PI_2 = 1.57079632679489661923132169163975144;
+#endif
+    *v = (theta + ((g_flags & ORC_UV_BOOK) ? FRAC_PI_2 : FRAC_2_PI)) / PI; /* sic: FRAC_2_PI, not FRAC_PI_2 */
 }
 
 /* sphere.rs:37-77 and :122-164 (identical bodies, centre differs) */

@@ -9,7 +9,7 @@ import os
 
 from . import build as _build
 
-RTMI_ABI_VERSION = 4
+RTMI_ABI_VERSION = 5
 RTMI_MAX_BVH_DEPTH = 24
 RTMI_TILE = 8
 RTMI_FLAG_FAST_CULL = 1
@@ -19,6 +19,12 @@ RTMI_FLAG_SYNC = 8
 RTMI_FLAG_ASYNC = 16
 RTMI_FLAG_SKY = 32
 RTMI_FLAG_REF_TREE = 64
+RTMI_FLAG_FACE_FORWARD = 128
+RTMI_FLAG_UV_BOOK = 4096
+RTMI_FLAG_TEST_OVERFLOW = 8192
+RTMI_ERR_DEVICE = 3
+RTMI_ERR_CANCELLED = 5
+RTMI_TEXEL_POISON = 0x80000000
 
 TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
@@ -95,7 +101,12 @@ class RenderParams(C.Structure):
     _fields_ = [("nx", C.c_uint32), ("ny", C.c_uint32), ("ns", C.c_uint32), ("max_depth", C.c_uint32),
                 ("t_min", C.c_float), ("flags", C.c_uint32), ("seed", C.c_uint64),
                 ("tile_rank", C.c_uint32), ("tile_world", C.c_uint32), ("spp_chunks", C.c_uint32), ("shade_threshold", C.c_uint32),
-                ("path_sig", C.c_uint64), ("prof", C.c_uint64), ("sample_buffer_bytes", C.c_uint64)]
+                ("path_sig", C.c_uint64), ("prof", C.c_uint64), ("sample_buffer_bytes", C.c_uint64),
+                ("progress_fn", C.c_uint64), ("progress_user", C.c_uint64)]
+
+
+# rtmi_progress_fn: int (*)(uint64_t done, uint64_t total, void *user)
+PROGRESS_FN = C.CFUNCTYPE(C.c_int, C.c_uint64, C.c_uint64, C.c_void_p)
 
 
 class Texel(C.Structure):
@@ -109,8 +120,8 @@ class Stats(C.Structure):
 
 # every entry point include/rtmi.h declares (tests check that the library exports them all)
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_local_tiles",
-                "rtmi_render_prepare", "rtmi_render_device", "rtmi_render", "rtmi_untile", "rtmi_ppm_p3", "rtmi_probe_math",
-                "rtmi_probe_philox", "rtmi_probe_xform"]
+                "rtmi_render_prepare", "rtmi_render_device", "rtmi_scene_status", "rtmi_render", "rtmi_render_multi", "rtmi_untile",
+                "rtmi_ppm_p3", "rtmi_probe_math", "rtmi_probe_philox", "rtmi_probe_xform"]
 
 _rtmi = None
 _host = None
@@ -136,6 +147,13 @@ def load_rtmi():
     lib.rtmi_local_tiles.argtypes = [C.POINTER(RenderParams)]
     lib.rtmi_render_device.restype = C.c_int
     lib.rtmi_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    lib.rtmi_scene_status.restype = C.c_int
+    lib.rtmi_scene_status.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.rtmi_render_prepare.restype = C.c_int
+    lib.rtmi_render_prepare.argtypes = [vp, C.POINTER(RenderParams)]
+    lib.rtmi_render_multi.restype = C.c_int
+    lib.rtmi_render_multi.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.POINTER(Camera), C.POINTER(RenderParams),
+                                      vp, vp, C.POINTER(Stats)]
     lib.rtmi_render.restype = C.c_int
     lib.rtmi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
     lib.rtmi_untile.restype = C.c_int
@@ -200,6 +218,8 @@ def load_host():
         "rth_render": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]),
         "rth_render_device": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]),
         "rth_render_prepare": (i, [vp, C.POINTER(RenderParams)]),
+        "rth_scene_status": (i, [vp]),
+        "rth_render_multi": (i, [vp, vp, C.POINTER(RenderParams), C.POINTER(C.c_int), u32, vp, vp, C.POINTER(Stats)]),
         "rth_camera_render": (i, [vp, vp, u32, u32, u32, u64, u32, i, vp, vp, C.POINTER(Stats)]),
         "rth_hit": (i, [vp, vp, vp, d, d, d, u64, vp, vp]),
         "rth_bounding_box": (i, [vp, d, d, vp, vp]),
@@ -208,6 +228,8 @@ def load_host():
         "rth_emitted": (i, [vp, d, d, vp, vp]),
         "rth_get_ray": (i, [vp, d, d, u64, vp]),
         "rth_set_sky_background": (None, [i]),
+        "rth_set_face_forward": (None, [i]),
+        "rth_set_uv_book": (None, [i]),
         "rth_color_sample": (i, [vp, vp, u32, u32, u32, u32, u32, u64, vp]),
     }
     for name, (res, args) in sig.items():

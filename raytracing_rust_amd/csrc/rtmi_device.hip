@@ -16,10 +16,16 @@
 // include/rtmi_math.h.  Every device function cites the reference lines it implements.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <time.h>
+
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "rtmi.h"
@@ -53,12 +59,19 @@ struct rtmi_scene {
     size_t samples_bytes = 0;
     uint2 *spill = nullptr;    // global part of the cooperative traversal stacks [wavefront slot][spill_cap]
     size_t spill_bytes = 0;
-    unsigned int *status = nullptr; // device words: [0] cooperative-traversal pool overflows (must stay 0),
-                                    // [1] unit counter of the persistent wavefronts
+    unsigned int *status = nullptr; // RTMI_STATUS_WORDS device words, see rtmi_types.hpp
     int slots = 0;                  // CUs x 16: resident wavefronts the render kernels are launched with
     bool has_alt = false;           // some BVH item carries an alternative tree
-    rtmi_texel *texels = nullptr; // scratch for the blocking host API
+    // scratch of the blocking host API (grow-only, so a host that renders frame after frame allocates once)
+    rtmi_texel *texels = nullptr;
     size_t texel_count = 0;
+    unsigned long long *d_sig = nullptr;
+    size_t sig_count = 0;
+    std::vector<rtmi_texel> h_texels;
+    std::vector<unsigned long long> h_sig;
+    hipStream_t stream = nullptr;      // launches of the blocking API (non-blocking stream)
+    hipStream_t copy_stream = nullptr; // progress polls while a launch runs
+    uint64_t units_total = 0;          // work units of the last enqueued call (progress denominator)
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
@@ -89,6 +102,10 @@ static int validate(const rtmi_scene_desc *d) {
     if (d->max_bvh_depth > RTMI_MAX_BVH_DEPTH)
         return fail(RTMI_ERR_UNSUPPORTED, "BVH deeper than RTMI_MAX_BVH_DEPTH");
     if (d->n_prims >= (1u << 28)) return fail(RTMI_ERR_UNSUPPORTED, "too many primitives");
+    if ((d->n_prims && (!d->prim_a || !d->prim_b || !d->prim_meta)) || (d->n_nodes && !d->nodes) || (d->n_xforms && !d->xforms) ||
+        (d->n_materials && !d->materials) || (d->n_textures && !d->textures) || (d->n_perlin && !d->perlin) ||
+        (d->n_images && !d->images) || (d->image_bytes && !d->image_data))
+        return fail(RTMI_ERR_INVALID, "a non-zero count comes with a NULL array");
     auto prim_ok = [&](int64_t i) { return i >= 0 && (uint64_t)i < d->n_prims; };
     for (uint32_t i = 0; i < d->n_prims; i++) {
         const rtmi_prim_meta &m = d->prim_meta[i];
@@ -108,6 +125,49 @@ static int validate(const rtmi_scene_desc *d) {
             }
         }
     }
+    // alternative-tree records: children in range, leaves typed like the primitive they name
+    if (d->n_alt_nodes && !d->alt_nodes) return fail(RTMI_ERR_INVALID, "n_alt_nodes without alt_nodes");
+    for (uint32_t i = 0; i < d->n_alt_nodes; i++)
+        for (int c = 0; c < 4; c++) {
+            const int32_t ch = d->alt_nodes[i].child[c];
+            if (ch == RTMI_NO_CHILD) continue;
+            if (ch >= 0) {
+                if ((uint32_t)ch >= d->n_alt_nodes) return fail(RTMI_ERR_INVALID, "alternative tree child out of range");
+            } else {
+                const uint32_t type = ((uint32_t)ch >> 28) & 7u, idx = (uint32_t)ch & 0x0fffffffu;
+                if (type > RTMI_PRIM_CUBE || !prim_ok(idx)) return fail(RTMI_ERR_INVALID, "alternative tree leaf out of range");
+                if ((int)type != d->prim_meta[idx].type) return fail(RTMI_ERR_INVALID, "alternative tree leaf type mismatch");
+            }
+        }
+    // Walk every tree from its item's root.  The kernels size their traversal stacks from the DECLARED depths
+    // (fixed RTMI_MAX_BVH_DEPTH-entry LDS stack per lane; pool spill capacity), and a persistent wavefront that
+    // follows a child cycle never ends: each node may be reached once (no cycles, no shared subtrees) and no
+    // deeper than declared.  Depth of a root = 1, as the lowering counts it.
+    std::vector<uint8_t> seen_bin(d->n_nodes, 0), seen_alt(d->n_alt_nodes, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> todo; // (node, depth)
+    const auto walk = [&](bool alt, uint32_t root, uint32_t declared, const char *what) -> int {
+        std::vector<uint8_t> &seen = alt ? seen_alt : seen_bin;
+        todo.clear();
+        todo.emplace_back(root, 1u);
+        while (!todo.empty()) {
+            const uint32_t n = todo.back().first, depth = todo.back().second;
+            todo.pop_back();
+            if (seen[n]) return fail(RTMI_ERR_INVALID, std::string(what) + ": a node is reached twice (cycle or shared subtree)");
+            seen[n] = 1;
+            if (depth > declared) return fail(RTMI_ERR_INVALID, std::string(what) + " is deeper than the declared depth");
+            if (alt) {
+                for (int c = 0; c < 4; c++) {
+                    const int32_t ch = d->alt_nodes[n].child[c];
+                    if (ch >= 0 && ch != RTMI_NO_CHILD) todo.emplace_back((uint32_t)ch, depth + 1u);
+                }
+            } else {
+                const int32_t l = d->nodes[n].left, r = d->nodes[n].right;
+                if (l >= 0) todo.emplace_back((uint32_t)l, depth + 1u);
+                if (r >= 0) todo.emplace_back((uint32_t)r, depth + 1u); // an internal child listed twice is caught by `seen`
+            }
+        }
+        return RTMI_OK;
+    };
     for (uint32_t i = 0; i < d->n_items; i++) {
         const rtmi_item &it = d->items[i];
         if (it.kind == RTMI_ITEM_LIST) {
@@ -116,8 +176,13 @@ static int validate(const rtmi_scene_desc *d) {
                 return fail(RTMI_ERR_INVALID, "item primitive range out of bounds");
         } else if (it.kind == RTMI_ITEM_BVH) {
             if (it.first < 0 || (uint32_t)it.first >= d->n_nodes) return fail(RTMI_ERR_INVALID, "item BVH root out of range");
-            if (it.alt_first >= 0 && ((uint32_t)it.alt_first >= d->n_alt_nodes || !d->prim_gate || !d->alt_nodes))
-                return fail(RTMI_ERR_INVALID, "item alternative tree out of range or prim_gate missing");
+            if (int rc = walk(false, (uint32_t)it.first, d->max_bvh_depth, "BVH")) return rc;
+            if (it.alt_first >= 0) {
+                if ((uint32_t)it.alt_first >= d->n_alt_nodes || !d->prim_gate || !d->alt_nodes)
+                    return fail(RTMI_ERR_INVALID, "item alternative tree out of range or prim_gate missing");
+                if (d->alt_max_depth > 64u) return fail(RTMI_ERR_UNSUPPORTED, "alternative tree deeper than 64");
+                if (int rc = walk(true, (uint32_t)it.alt_first, d->alt_max_depth, "alternative tree")) return rc;
+            }
         } else {
             return fail(RTMI_ERR_INVALID, "bad item kind");
         }
@@ -193,10 +258,7 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
             for (rtmi_bvh4_node &n : alt)
                 for (int c = 0; c < 4; c++) {
                     if (n.child[c] == RTMI_NO_CHILD) n.child[c] = (int32_t)0xffffffffu;
-                    else {
-                        if (n.child[c] >= 0 && (uint32_t)n.child[c] >= d->n_alt_nodes) rc = fail(RTMI_ERR_INVALID, "alternative tree child out of range");
-                        n.child[c] = enc(n.child[c]);
-                    }
+                    else n.child[c] = enc(n.child[c]); // range-checked by validate()
                 }
             if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(alt.data()), (size_t)d->n_alt_nodes * 8, &s->dev.nodes4);
         }
@@ -215,8 +277,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     for (uint32_t i = 0; i < d->n_items; i++)
         if (d->items[i].kind == RTMI_ITEM_BVH && d->items[i].alt_first >= 0) s->has_alt = true;
     s->dev.n_items = d->n_items;
-    if (hipMalloc(reinterpret_cast<void **>(&s->status), 2 * sizeof(unsigned int)) != hipSuccess ||
-        hipMemset(s->status, 0, 2 * sizeof(unsigned int)) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&s->status), RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess ||
+        hipMemset(s->status, 0, RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess) {
         rtmi_scene_destroy(s);
         return fail(RTMI_ERR_DEVICE, "allocating the status word failed");
     }
@@ -242,7 +304,10 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (s->samples) (void)hipFree(s->samples);
     if (s->spill) (void)hipFree(s->spill);
     if (s->texels) (void)hipFree(s->texels);
+    if (s->d_sig) (void)hipFree(s->d_sig);
     if (s->status) (void)hipFree(s->status);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     for (int i = 0; i < 3; i++)
         if (s->ev[i]) (void)hipEventDestroy(s->ev[i]);
     delete s;
@@ -397,6 +462,12 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     P.status = s->status;
     P.queue = s->status + 1;
     P.sky = (p->flags & RTMI_FLAG_SKY) ? 1u : 0u;
+    P.ext = ((p->flags & RTMI_FLAG_FACE_FORWARD) ? RTMI_EXT_FACE_FORWARD : 0u) | ((p->flags & RTMI_FLAG_UV_BOOK) ? RTMI_EXT_UV_BOOK : 0u) |
+            ((p->flags & RTMI_FLAG_TEST_OVERFLOW) ? RTMI_EXT_TEST_OVERFLOW : 0u);
+    // this call's overflow word, the unit counter and the finished-units word start at zero; the sticky word stays
+    HIP_TRY(hipMemsetAsync(s->status, 0, 2 * sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(s->status + 3, 0, sizeof(unsigned int), stream));
+    s->units_total = 0;
     // LDS part of the traversal stack: 512 entries cover the deepest stack ever seen on the reference scenes
     // (447); deeper stacks continue in global memory (64 * (depth + 2) entries per wavefront, the bound of the
     // depth-first order), so the LDS footprint (7.7 KB per wavefront) does not depend on the tree depth
@@ -435,7 +506,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
                                    : (nitems < (uint64_t)s->slots ? nitems : (uint64_t)s->slots);
     const dim3 grid((uint32_t)nblocks);
     blocks_total += grid.x; chunks_total += P.nchunks;
-    HIP_TRY(hipMemsetAsync(s->status + 1, 0, sizeof(unsigned int), stream));
+    s->units_total += nitems;
 #define RTMI_LAUNCH(KERN, F, S, PR, LDS) hipLaunchKernelGGL((KERN<F, S, PR>), grid, block, LDS, stream, s->dev, C, P)
 #define RTMI_LAUNCH_COOP(S, PR, W, E)                                                                                    \
     do {                                                                                                                 \
@@ -472,6 +543,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     if (stats && last) HIP_TRY(hipEventRecord(s->ev[1], stream));
     hipLaunchKernelGGL(rtmi_resolve_kernel, dim3((ntex + 255) / 256), dim3(256), 0, stream, s->samples, s->partial,
                        reinterpret_cast<rtmi_texel *>(d_texels), P, s0 == 0 ? 1 : 0, last ? 1 : 0);
+    hipLaunchKernelGGL(rtmi_pass_end_kernel, dim3(1), dim3(1), 0, stream, s->status, (unsigned int)nitems, last ? 1 : 0);
     HIP_TRY(hipGetLastError());
     } // passes
     if (stats) {
@@ -494,9 +566,26 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
         }
         stats->samples = pix * p->ns;
         stats->tiles = P.ntiles_local; stats->chunks = chunks_total; stats->blocks = blocks_total; stats->reserved = 0;
-        unsigned int st = 0;
+        unsigned int st = 0; // this call's overflow word (the kernels have finished: ev[2] was waited for)
         HIP_TRY(hipMemcpy(&st, s->status, sizeof(st), hipMemcpyDeviceToHost));
-        if (st != 0) return fail(RTMI_ERR_DEVICE, "cooperative traversal pool overflow (results invalid): use RTMI_FLAG_SYNC");
+        if (st != 0) {
+            HIP_TRY(hipMemset(s->status + 2, 0, sizeof(unsigned int))); // reported here: not again by rtmi_scene_status
+            return fail(RTMI_ERR_DEVICE, "cooperative traversal pool overflow (results invalid, texels poisoned): use RTMI_FLAG_SYNC");
+        }
+    }
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_scene_status(rtmi_scene *s, uint32_t *overflows) {
+    if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned int st = 0;
+    HIP_TRY(hipMemcpy(&st, s->status + 2, sizeof(st), hipMemcpyDeviceToHost));
+    if (overflows) *overflows = st;
+    if (st != 0) {
+        HIP_TRY(hipMemset(s->status + 2, 0, sizeof(unsigned int)));
+        return fail(RTMI_ERR_DEVICE, "cooperative traversal pool overflow in an earlier render call (its texels are poisoned): use RTMI_FLAG_SYNC");
     }
     return RTMI_OK;
 }
@@ -519,6 +608,8 @@ extern "C" int rtmi_untile(const rtmi_render_params *p, const rtmi_texel *g, flo
                     const uint32_t px = tx * RTMI_TILE + lx;
                     if (px >= p->nx) break;
                     const rtmi_texel &e = src[ly * RTMI_TILE + lx];
+                    if (e.rgb8 & RTMI_TEXEL_POISON)
+                        return fail(RTMI_ERR_DEVICE, "framebuffer holds poisoned texels (traversal pool overflow in the launch that wrote them)");
                     const size_t o = ((size_t)row * p->nx + px) * 3;
                     if (out_linear) { out_linear[o] = e.r; out_linear[o + 1] = e.g; out_linear[o + 2] = e.b; }
                     if (out_rgb8) {
@@ -532,6 +623,84 @@ extern "C" int rtmi_untile(const rtmi_render_params *p, const rtmi_texel *g, flo
     return RTMI_OK;
 }
 
+// ---- blocking host API ---------------------------------------------------------------------------------
+static int ensure_streams(rtmi_scene *s) {
+    if (!s->stream) HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    if (!s->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    return RTMI_OK;
+}
+// Waits for `done_ev` of every listed scene; meanwhile (about every 50 ms) reads the devices' unit counters through
+// their copy streams and reports progress to the caller's callback — what src/progressbar.rs:6-58 only pretends to.
+static int wait_with_progress(rtmi_scene *const *scenes, hipEvent_t *done_ev, uint32_t n, const rtmi_render_params *p) {
+    rtmi_progress_fn fn = reinterpret_cast<rtmi_progress_fn>(static_cast<uintptr_t>(p->progress_fn));
+    void *user = reinterpret_cast<void *>(static_cast<uintptr_t>(p->progress_user));
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) total += scenes[i]->units_total;
+    bool cancelled = false;
+    uint64_t shown = 0;
+    if (fn) {
+        for (;;) {
+            bool all_done = true;
+            uint64_t done = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                rtmi_scene *s = scenes[i];
+                HIP_TRY(hipSetDevice(s->device));
+                const hipError_t q = hipEventQuery(done_ev[i]);
+                if (q == hipErrorNotReady) {
+                    all_done = false;
+                    unsigned int w[RTMI_STATUS_WORDS] = {0, 0, 0, 0};
+                    HIP_TRY(hipMemcpyAsync(w, s->status, sizeof(w), hipMemcpyDeviceToHost, s->copy_stream));
+                    HIP_TRY(hipStreamSynchronize(s->copy_stream));
+                    const uint64_t d = (uint64_t)w[3] + w[1]; // finished passes + units handed out in the running one
+                    done += d < s->units_total ? d : s->units_total;
+                } else if (q == hipSuccess) {
+                    done += s->units_total;
+                } else {
+                    return fail(RTMI_ERR_DEVICE, std::string("hipEventQuery: ") + hipGetErrorString(q));
+                }
+            }
+            if (all_done) break;
+            if (done < shown) done = shown; // the two words are read without a lock: keep the report monotone
+            shown = done;
+            if (!cancelled && fn(done, total, user) != 0) cancelled = true;
+            struct timespec ts = {0, 50 * 1000 * 1000};
+            nanosleep(&ts, nullptr);
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(scenes[i]->device));
+        HIP_TRY(hipEventSynchronize(done_ev[i]));
+    }
+    if (fn && !cancelled && fn(total, total, user) != 0) cancelled = true;
+    return cancelled ? fail(RTMI_ERR_CANCELLED, "cancelled by the progress callback") : RTMI_OK;
+}
+// this call's overflow word of a scene whose kernels have finished
+static int check_overflow(rtmi_scene *s) {
+    unsigned int st = 0;
+    HIP_TRY(hipMemcpy(&st, s->status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st != 0) {
+        HIP_TRY(hipMemset(s->status + 2, 0, sizeof(unsigned int)));
+        return fail(RTMI_ERR_DEVICE, "cooperative traversal pool overflow (results invalid, texels poisoned): use RTMI_FLAG_SYNC");
+    }
+    return RTMI_OK;
+}
+static void fill_stats(rtmi_scene *s, const rtmi_render_params *p, rtmi_stats *stats, float ms_render, float ms_all) {
+    stats->render_ms = ms_render;
+    stats->kernel_ms = ms_all;
+    uint64_t pix = 0;
+    const uint32_t txn = tiles_x_of(p), nl = local_tiles_of(p, p->tile_rank);
+    for (uint32_t lt = 0; lt < nl; lt++) {
+        const uint32_t t = lt * p->tile_world + p->tile_rank;
+        const uint32_t ty = t / txn, tx = t % txn;
+        const uint32_t w = (tx * RTMI_TILE + RTMI_TILE <= p->nx) ? RTMI_TILE : p->nx - tx * RTMI_TILE;
+        const uint32_t h = (ty * RTMI_TILE + RTMI_TILE <= p->ny) ? RTMI_TILE : p->ny - ty * RTMI_TILE;
+        pix += (uint64_t)w * h;
+    }
+    stats->samples = pix * p->ns;
+    stats->tiles = nl; stats->chunks = 0; stats->blocks = 0; stats->reserved = 0;
+    (void)s;
+}
+
 extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p_in, float *out_linear,
                            uint8_t *out_rgb8, uint64_t *out_path_sig, rtmi_stats *stats) {
     if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
@@ -539,6 +708,7 @@ extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_ren
     if (rc) return rc;
     if (p_in->tile_world != 1) return fail(RTMI_ERR_INVALID, "rtmi_render renders the whole image: tile_world must be 1");
     HIP_TRY(hipSetDevice(s->device));
+    if ((rc = ensure_streams(s))) return rc;
     rtmi_render_params p = *p_in;
     const size_t ntex = (size_t)rtmi_local_tiles(&p) * 64;
     if (ntex > s->texel_count) {
@@ -546,32 +716,203 @@ extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_ren
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->texels), ntex * sizeof(rtmi_texel)));
         s->texel_count = ntex;
     }
-    unsigned long long *d_sig = nullptr;
     p.flags &= ~RTMI_FLAG_PATH_SIG;
     p.path_sig = 0;
     if (out_path_sig) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_sig), ntex * sizeof(unsigned long long)));
+        if (ntex > s->sig_count) {
+            if (s->d_sig) { HIP_TRY(hipFree(s->d_sig)); s->d_sig = nullptr; s->sig_count = 0; }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_sig), ntex * sizeof(unsigned long long)));
+            s->sig_count = ntex;
+        }
         p.flags |= RTMI_FLAG_PATH_SIG;
-        p.path_sig = reinterpret_cast<uint64_t>(d_sig);
+        p.path_sig = reinterpret_cast<uint64_t>(s->d_sig);
     }
-    rtmi_stats local{};
-    rc = rtmi_render_device(s, cam, &p, s->texels, nullptr, stats ? stats : &local);
-    if (rc) { if (d_sig) (void)hipFree(d_sig); return rc; }
-    std::vector<rtmi_texel> host(ntex);
-    HIP_TRY(hipMemcpy(host.data(), s->texels, ntex * sizeof(rtmi_texel), hipMemcpyDeviceToHost));
+    if (p.progress_fn) {
+        // asynchronous launch, then wait and report progress; stats from the scene's events afterwards
+        HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+        rc = rtmi_render_device(s, cam, &p, s->texels, s->stream, nullptr);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(s->ev[2], s->stream));
+        rtmi_scene *one[1] = {s};
+        rc = wait_with_progress(one, &s->ev[2], 1, &p);
+        if (rc) return rc;
+        if ((rc = check_overflow(s))) return rc;
+        if (stats) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev[0], s->ev[2]));
+            fill_stats(s, &p, stats, ms, ms);
+        }
+    } else {
+        rtmi_stats local{};
+        rc = rtmi_render_device(s, cam, &p, s->texels, s->stream, stats ? stats : &local);
+        if (rc) return rc;
+    }
+    s->h_texels.resize(ntex);
+    HIP_TRY(hipMemcpy(s->h_texels.data(), s->texels, ntex * sizeof(rtmi_texel), hipMemcpyDeviceToHost));
     if (out_path_sig) {
-        std::vector<unsigned long long> hs(ntex);
-        hipError_t e = hipMemcpy(hs.data(), d_sig, ntex * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-        (void)hipFree(d_sig);
-        if (e != hipSuccess) return fail(RTMI_ERR_DEVICE, "copying the path signature failed");
+        s->h_sig.resize(ntex);
+        HIP_TRY(hipMemcpy(s->h_sig.data(), s->d_sig, ntex * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         const uint32_t txn = tiles_x_of(&p);
         for (uint32_t row = 0; row < p.ny; row++)
             for (uint32_t px = 0; px < p.nx; px++) {
                 const uint32_t t = (row / RTMI_TILE) * txn + px / RTMI_TILE;
-                out_path_sig[(size_t)row * p.nx + px] = hs[(size_t)t * 64 + (row % RTMI_TILE) * RTMI_TILE + px % RTMI_TILE];
+                out_path_sig[(size_t)row * p.nx + px] = s->h_sig[(size_t)t * 64 + (row % RTMI_TILE) * RTMI_TILE + px % RTMI_TILE];
             }
     }
-    return rtmi_untile(&p, host.data(), out_linear, out_rgb8);
+    return rtmi_untile(&p, s->h_texels.data(), out_linear, out_rgb8);
+}
+
+// ---- several GPUs of this process: scene replicated, tiles t % n, one gather on devices[0] --------------------
+// RCCL is bound lazily (dlopen) so that single-GPU users of librtmi.so do not load it; inside a PyTorch process the
+// soname resolves to the copy torch already mapped.
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Gather)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr; // rccl.h ncclGather
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+        }
+        if (!lib) { err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found"); return false; }
+        CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+        CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+        GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+        GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+        Gather = reinterpret_cast<decltype(Gather)>(dlsym(lib, "ncclGather"));
+        GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Gather || !GetErrorString) {
+            err = "librccl lacks one of ncclCommInitAll/ncclCommDestroy/ncclGroupStart/ncclGroupEnd/ncclGather/ncclGetErrorString";
+            dlclose(lib); lib = nullptr;
+            return false;
+        }
+        return true;
+    }
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+std::map<std::vector<int>, std::vector<void *>> g_comms; // one communicator set per device list, for the process lifetime
+} // namespace
+#define RCCL_TRY(expr)                                                                                        \
+    do {                                                                                                      \
+        int r_ = (expr);                                                                                      \
+        if (r_ != 0) return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));     \
+    } while (0)
+
+namespace {
+struct MultiState { // frees what rtmi_render_multi created, on every return path
+    std::vector<rtmi_scene *> scenes;
+    std::vector<rtmi_texel *> texels;
+    std::vector<int> devices;
+    rtmi_texel *gathered = nullptr;
+    ~MultiState() {
+        for (size_t i = 0; i < texels.size(); i++)
+            if (texels[i]) { (void)hipSetDevice(devices[i]); (void)hipFree(texels[i]); }
+        if (gathered) { (void)hipSetDevice(devices[0]); (void)hipFree(gathered); }
+        for (rtmi_scene *s : scenes) rtmi_scene_destroy(s);
+    }
+};
+} // namespace
+
+extern "C" int rtmi_render_multi(const rtmi_scene_desc *desc, const int *devices, uint32_t n, const rtmi_camera *cam,
+                                 const rtmi_render_params *p_in, float *out_linear, uint8_t *out_rgb8, rtmi_stats *stats) {
+    if (!desc || !devices || !cam || n == 0) return fail(RTMI_ERR_INVALID, "NULL argument or empty device list");
+    int rc = check_params(p_in);
+    if (rc) return rc;
+    if (p_in->tile_world != 1 || p_in->tile_rank != 0)
+        return fail(RTMI_ERR_INVALID, "rtmi_render_multi renders the whole image: tile_rank/tile_world must be 0/1");
+    if (p_in->flags & (RTMI_FLAG_PATH_SIG | RTMI_FLAG_PROFILE)) return fail(RTMI_ERR_INVALID, "PATH_SIG / PROFILE are single-device diagnostics");
+    const int ndev = rtmi_device_count();
+    if (ndev <= 0) return fail(RTMI_ERR_DEVICE, "no HIP device available (the rtmi path has no CPU fallback)");
+    bool distinct = true;
+    for (uint32_t i = 0; i < n; i++) {
+        if (devices[i] < 0 || devices[i] >= ndev) return fail(RTMI_ERR_INVALID, "device index out of range");
+        for (uint32_t k = 0; k < i; k++) distinct = distinct && devices[k] != devices[i];
+    }
+    MultiState st;
+    st.devices.assign(devices, devices + n);
+    st.scenes.assign(n, nullptr);
+    st.texels.assign(n, nullptr);
+    std::vector<rtmi_render_params> params(n, *p_in);
+    params[0].tile_world = n; params[0].tile_rank = 0;
+    const size_t stride = (size_t)local_tiles_of(&params[0], 0) * 64; // every rank padded to rank 0's size (the largest)
+    std::vector<hipEvent_t> done(n);
+    for (uint32_t i = 0; i < n; i++) {
+        params[i].tile_world = n; params[i].tile_rank = i;
+        if ((rc = rtmi_scene_create(desc, devices[i], &st.scenes[i]))) return rc;
+        HIP_TRY(hipSetDevice(devices[i]));
+        if ((rc = ensure_streams(st.scenes[i]))) return rc;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st.texels[i]), stride * sizeof(rtmi_texel)));
+        HIP_TRY(hipMemsetAsync(st.texels[i], 0, stride * sizeof(rtmi_texel), st.scenes[i]->stream));
+        done[i] = st.scenes[i]->ev[2];
+    }
+    HIP_TRY(hipSetDevice(devices[0]));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st.gathered), (size_t)n * stride * sizeof(rtmi_texel)));
+    std::vector<void *> comms;
+    if (distinct && n > 1) {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        if (!g_rccl.load()) return fail(RTMI_ERR_DEVICE, g_rccl.err);
+        auto it = g_comms.find(st.devices);
+        if (it == g_comms.end()) {
+            std::vector<void *> c(n, nullptr);
+            RCCL_TRY(g_rccl.CommInitAll(c.data(), (int)n, devices));
+            it = g_comms.emplace(st.devices, c).first;
+        }
+        comms = it->second;
+    }
+    // every device renders its tiles on its own stream, all concurrently
+    for (uint32_t i = 0; i < n; i++) {
+        rtmi_scene *s = st.scenes[i];
+        HIP_TRY(hipSetDevice(devices[i]));
+        HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+        if ((rc = rtmi_render_device(s, cam, &params[i], st.texels[i], s->stream, nullptr))) return rc;
+        HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+    }
+    // the ONE exchange of the path: tile-packed framebuffers -> devices[0]
+    if (!comms.empty()) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (uint32_t i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(devices[i]));
+            RCCL_TRY(g_rccl.Gather(st.texels[i], i == 0 ? st.gathered : nullptr, stride * sizeof(rtmi_texel), /*ncclInt8*/ 0, 0, comms[i], st.scenes[i]->stream));
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+    } else {
+        for (uint32_t i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(devices[i]));
+            HIP_TRY(hipMemcpyPeerAsync(st.gathered + (size_t)i * stride, devices[0], st.texels[i], devices[i], stride * sizeof(rtmi_texel), st.scenes[i]->stream));
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(devices[i]));
+        HIP_TRY(hipEventRecord(st.scenes[i]->ev[2], st.scenes[i]->stream));
+    }
+    if ((rc = wait_with_progress(st.scenes.data(), done.data(), n, p_in))) return rc;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    for (uint32_t i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(devices[i]));
+        if ((rc = check_overflow(st.scenes[i]))) return rc;
+        if (stats) {
+            float ms_r = 0.f, ms_all = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms_r, st.scenes[i]->ev[0], st.scenes[i]->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&ms_all, st.scenes[i]->ev[0], st.scenes[i]->ev[2]));
+            rtmi_stats one{};
+            fill_stats(st.scenes[i], &params[i], &one, ms_r, ms_all);
+            stats->samples += one.samples; stats->tiles += one.tiles;
+            if (one.render_ms > stats->render_ms) stats->render_ms = one.render_ms;
+            if (one.kernel_ms > stats->kernel_ms) stats->kernel_ms = one.kernel_ms;
+        }
+    }
+    HIP_TRY(hipSetDevice(devices[0]));
+    std::vector<rtmi_texel> host((size_t)n * stride);
+    HIP_TRY(hipMemcpy(host.data(), st.gathered, host.size() * sizeof(rtmi_texel), hipMemcpyDeviceToHost));
+    return rtmi_untile(&params[0], host.data(), out_linear, out_rgb8);
 }
 
 // P3 writer — tests/test.rs:59,79

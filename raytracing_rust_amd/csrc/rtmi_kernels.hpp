@@ -115,7 +115,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
         if (have_hit) {
             have_hit = false;
             if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
-            if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+            if (!shade_hit(sc, P.max_depth, P.ext, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
                 // absorbed, emitter or depth limit: the path ends
                 path_end(P, oidx, pa);
                 if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
         if (have_hit) {
             have_hit = false;
             if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
-            if (!shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+            if (!shade_hit(sc, P.max_depth, P.ext, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
                 path_end(P, oidx, pa);
                 if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
                 alive = false;
@@ -255,6 +255,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
         }
         prof_time<PROF>(prof, 30, tstamp); // shading
     }
+    if (P.ext & RTMI_EXT_TEST_OVERFLOW) overflow = true; // test knob: exercise the error path
     if (__ballot(overflow) != 0ull && lane == 0) atomicAdd(P.status, 1u); // reported loudly by the host
 
     if (PROF) {
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
         } else if (run == ST_SHADE) {
             if (st == ST_SHADE) {
                 if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
-                if (shade_hit(sc, P.max_depth, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+                if (shade_hit(sc, P.max_depth, P.ext, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
                     W.o = pa.ro; W.d = pa.rd;
                     ray_derive(W);
                     it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;
@@ -535,6 +536,9 @@ __global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restr
                                                            rtmi_texel *__restrict__ out, DevParams P, int first, int last) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= P.ntiles_local * 64u) return;
+    // a traversal-pool overflow in any pass of this call invalidates its texels: poison them (rtmi_untile and
+    // rtmi_scene_status report it) instead of handing out plausible numbers
+    const bool poisoned = P.status[0] != 0u;
     const uint32_t ltile = tid >> 6, lane = tid & 63u;
     const uint32_t tile = ltile * P.tile_world + P.tile_rank;
     const uint32_t ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
@@ -572,7 +576,19 @@ __global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restr
     }
     tx_out.r = lin[0]; tx_out.g = lin[1]; tx_out.b = lin[2];
     tx_out.rgb8 = q[0] | (q[1] << 8) | (q[2] << 16);
+    if (poisoned) {
+        const float nan = __uint_as_float(0x7fc00000u);
+        tx_out.r = nan; tx_out.g = nan; tx_out.b = nan;
+        tx_out.rgb8 = RTMI_TEXEL_POISON;
+    }
     out[tid] = tx_out;
+}
+// end of a pass (one thread): the unit counter goes back to zero for the next pass, the pass's units are added to
+// the progress word, and after the last pass the call's overflow count joins the sticky word
+__global__ void rtmi_pass_end_kernel(unsigned int *status, unsigned int units, int last) {
+    status[3] += units;
+    status[1] = 0u;
+    if (last) status[2] += status[0];
 }
 
 // ---- device evaluation of the arithmetic contract, for parity tests --------------------

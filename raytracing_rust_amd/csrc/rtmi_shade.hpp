@@ -75,11 +75,12 @@ __device__ __forceinline__ F3 tex_value(const DevScene &sc, int tex, float u, fl
 }
 
 // get_sphere_uv — sphere.rs:9-15 (FRAC_2_PI, sic)
-__device__ __forceinline__ void sphere_uv(F3 n, float &u, float &v) {
+// book = RTMI_FLAG_UV_BOOK (opt-in): theta + pi/2 as in the book instead of the reference's 2/pi
+__device__ __forceinline__ void sphere_uv(F3 n, bool book, float &u, float &v) {
     const float phi = rtmi_atan2f(n.z, n.x);
     const float theta = rtmi_asinf(n.y);
     u = 1.0f - (phi + RTMI_PI_F) / (2.0f * RTMI_PI_F);
-    v = (theta + RTMI_2_OVER_PI_F) / RTMI_PI_F;
+    v = (theta + (book ? RTMI_PIO2_F : RTMI_2_OVER_PI_F)) / RTMI_PI_F;
 }
 
 // ----------------------------------------------------------------------------------
@@ -177,7 +178,7 @@ __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, f
 // HitRecord of the closest hit (hittable.rs:9-16), built once, then
 // color(): emitted + attenuation * color(scattered) — color.rs:8-15, in throughput form.
 // Returns true when the path continues (pa holds the scattered ray), false when it ended.
-__device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth, Rng &g, uint32_t k0, uint32_t k1,
+__device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth, uint32_t ext, Rng &g, uint32_t k0, uint32_t k1,
                                           float closest, int best_item, int best_pf, bool best_medium, Path &pa) {
     const rtmi_item I = sc.items[best_item];
     F3 hp, hn;
@@ -200,7 +201,7 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
             F3 c = f3(A.x, A.y, A.z);
             if (M.type == RTMI_PRIM_MSPHERE) c = moving_center(A, sc.prim_b[idx], M.inv_dt, pa.rtime);
             hn = vdiv(hp - c, A.w); // sphere.rs:50 — outward, never face-forwarded
-            if (needs_uv) sphere_uv(hn, hu, hv);
+            if (needs_uv) sphere_uv(hn, (ext & RTMI_EXT_UV_BOOK) != 0u, hu, hv);
         } else {
             int plane;
             float x0, y0, x1, y1;
@@ -245,6 +246,8 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
     bool scattered = false;
     const F3 rd = pa.rd;
     F3 nd = rd, att = f3(1, 1, 1);
+    // opt-in RTMI_FLAG_FACE_FORWARD (wave-uniform): the opaque materials see the normal turned against the ray
+    if ((ext & RTMI_EXT_FACE_FORWARD) && kind != RTMI_MAT_DIELECTRIC && dot(rd, hn) > 0.0f) hn = -hn;
     if (can_scatter) {
         if (kind == RTMI_MAT_LAMBERTIAN) { // material.rs:49-53 (contract: dir = normal + rand)
             nd = hn + rs;

@@ -74,4 +74,12 @@ struct DevParams {
     unsigned int *queue; // next unit of the persistent wavefronts (zeroed before every launch)
     uint32_t sky; // RTMI_FLAG_SKY
     uint32_t use_alt; // cooperative kernel: walk the items' alternative trees, leaves accepted through their gate
+    uint32_t ext;     // opt-in extensions / test knobs: RTMI_EXT_*
 };
+#define RTMI_EXT_FACE_FORWARD 1u  // RTMI_FLAG_FACE_FORWARD
+#define RTMI_EXT_UV_BOOK 2u       // RTMI_FLAG_UV_BOOK
+#define RTMI_EXT_TEST_OVERFLOW 4u // RTMI_FLAG_TEST_OVERFLOW
+// status words of a scene (device memory): [0] wavefronts of the CURRENT render call that overflowed their traversal
+// pool (cleared at the start of every call), [1] unit counter of the persistent wavefronts (zero between passes),
+// [2] overflows accumulated until rtmi_scene_status() reports them, [3] units of the finished passes of this call
+#define RTMI_STATUS_WORDS 4

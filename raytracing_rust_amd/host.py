@@ -55,8 +55,19 @@ class _List(_Obj):
 
 
 def default_params(nx, ny, ns, seed=42, flags=0, max_depth=50, t_min=0.001, tile_rank=0, tile_world=1, spp_chunks=0,
-                   shade_threshold=0, sample_buffer_bytes=0):
+                   shade_threshold=0, sample_buffer_bytes=0, progress=None):
+    """progress: callable(done_units, total_units) -> falsy to go on / truthy to cancel; called from the blocking
+    render calls about every 50 ms (the object returned keeps the ctypes trampoline alive as `_progress_keep`)."""
     p = abi.RenderParams()
+    if progress is not None:
+        def _tramp(done, total, _user):
+            try:
+                return 1 if progress(int(done), int(total)) else 0
+            except Exception:  # nothing may unwind through the C ABI
+                return 1
+        cb = abi.PROGRESS_FN(_tramp)
+        p._progress_keep = cb
+        p.progress_fn = C.cast(cb, C.c_void_p).value
     p.nx, p.ny, p.ns = nx, ny, ns
     p.max_depth, p.t_min, p.flags, p.seed = max_depth, t_min, flags, seed
     p.tile_rank, p.tile_world, p.spp_chunks = tile_rank, tile_world, spp_chunks
@@ -126,6 +137,23 @@ class Scene:
         if sig:
             out["sig"] = sg
         return out
+
+    def render_multi(self, cam, nx, ny, ns, devices, **kw):
+        """Whole image on several GPUs of this process (rtmi_render_multi): tiles t % len(devices), one gather.
+        A device may be listed more than once (single-GPU rehearsal).  Bit-identical to render()."""
+        p = default_params(nx, ny, ns, **kw)
+        lin = np.zeros((ny, nx, 3), np.float32)
+        rgb = np.zeros((ny, nx, 3), np.uint8)
+        st = abi.Stats()
+        dev = (C.c_int * len(devices))(*devices)
+        self.host._check(self.host.lib.rth_render_multi(self.h, cam.h, C.byref(p), dev, len(devices), lin.ctypes.data,
+                                                         rgb.ctypes.data, C.byref(st)))
+        return {"linear": lin, "rgb8": rgb, "stats": _stats(st)}
+
+    def check_status(self):
+        """Raises if an asynchronous render_device() call since the last check overflowed its traversal pool."""
+        self.host._check(self.host.lib.rth_scene_status(self.h))
+        return self
 
     def local_tiles(self, params):
         return abi.load_rtmi().rtmi_local_tiles(C.byref(params))
@@ -326,14 +354,20 @@ class Host:
         self._check(self.lib.rth_emitted(mat.h, u, v, pp.ctypes.data, out.ctypes.data))
         return out
 
-    def color_sample(self, cam, world, nx, ny, i, j, s, seed=42, sky=False):
-        """color() of one camera sample on the CPU mirror; sky=True = the opt-in background of color.rs:18-20."""
+    def color_sample(self, cam, world, nx, ny, i, j, s, seed=42, sky=False, face_forward=False, uv_book=False):
+        """color() of one camera sample on the CPU mirror.  Opt-in extensions (off by default): sky = background of
+        color.rs:18-20; face_forward = opaque materials see the normal turned against the ray; uv_book = pi/2 in
+        get_sphere_uv instead of FRAC_2_PI (sphere.rs:13)."""
         out = np.zeros(3)
         self.lib.rth_set_sky_background(1 if sky else 0)
+        self.lib.rth_set_face_forward(1 if face_forward else 0)
+        self.lib.rth_set_uv_book(1 if uv_book else 0)
         try:
             self._check(self.lib.rth_color_sample(cam.h, world.h, nx, ny, i, j, s, seed, out.ctypes.data))
         finally:
             self.lib.rth_set_sky_background(0)
+            self.lib.rth_set_face_forward(0)
+            self.lib.rth_set_uv_book(0)
         return out
 
     def perlin_tables(self, tex):

@@ -114,11 +114,13 @@ std::optional<HitRecord> FlipNormals::hit(const Ray &ray, double t_min, double t
 std::optional<AABB> FlipNormals::bounding_box(double t0, double t1) const { return hittable_->bounding_box(t0, t1); }
 
 // ---- src/sphere.rs -----------------------------------------------------------------------
+static thread_local bool g_uv_book = false; // opt-in RTMI_FLAG_UV_BOOK for the CPU evaluation
+void set_uv_book(bool on) { g_uv_book = on; }
 static std::pair<double, double> get_sphere_uv(const Vec3 &p) { // :9-15
     const double phi = std::atan2(p.z, p.x);
     const double theta = std::asin(p.y);
     const double u = 1.0 - (phi + kPi) / (2.0 * kPi);
-    const double v = (theta + kFrac2Pi) / kPi; // sic
+    const double v = (theta + (g_uv_book ? kPi / 2.0 : kFrac2Pi)) / kPi; // FRAC_2_PI: sic (the book adds pi/2)
     return {u, v};
 }
 static std::optional<HitRecord> sphere_hit(const Vec3 &center, double radius, const Material *mat, const Ray &ray,
@@ -436,11 +438,16 @@ std::optional<std::pair<Ray, Vec3>> Isotropic::scatter(const Ray &ray, const Hit
 static thread_local bool g_sky_background = false;
 void set_sky_background(bool on) { g_sky_background = on; }
 bool sky_background() { return g_sky_background; }
+static thread_local bool g_face_forward = false; // opt-in RTMI_FLAG_FACE_FORWARD for the CPU evaluation
+void set_face_forward(bool on) { g_face_forward = on; }
 
 Vec3 color(const Ray &ray, const Hittable &world, size_t depth) {
     if (auto hit = world.hit(ray, 0.001, kF64Max)) {
         const Vec3 emitted = hit->material->emitted(hit->u, hit->v, hit->p);
         if (depth < 50) {
+            // extension: opaque materials see the normal turned against the ray; Dielectric resolves the side itself
+            if (g_face_forward && !dynamic_cast<const Dielectric *>(hit->material) && ray.direction().dot(hit->normal) > 0.0)
+                hit->normal = -hit->normal;
             if (auto sc = hit->material->scatter(ray, *hit))
                 return emitted + sc->second.zip_mul(color(sc->first, world, depth + 1));
         }
@@ -701,9 +708,13 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
             const double big = 3.40282346638528859811704183484516925e+38;
             AABB lb(Vec3(-big, -big, -big), Vec3(big, big, big));
             if (!unbounded_leaves && !dynamic_cast<const MovingSphere *>(h) && !dynamic_cast<const Rect *>(h)) {
-                if (auto b = h->bounding_box(0.0, 1.0)) {
+                // the primitive's TRUE extent (|radius| for a sphere), not bounding_box(): Sphere::bounding_box of a
+                // negative radius (the hollow-glass idiom) is an inverted box that no ray passes, and the reference has
+                // no leaf box test at all (bvh.rs:72-73)
+                AABB tl(Vec3(0, 0, 0), Vec3(0, 0, 0));
+                if (true_bounds(h, tl)) {
                     const Vec3 pd(pad, pad, pad);
-                    lb = AABB(b->min - pd, b->max + pd);
+                    lb = AABB(tl.min - pd, tl.max + pd);
                 }
             }
             rtmi_bvh_node &me = out.nodes[(size_t)id];
@@ -1023,20 +1034,33 @@ rtmi_camera Camera::lower() const {
     return c;
 }
 
+static int progress_trampoline(uint64_t done, uint64_t total, void *user) {
+    const auto *fn = static_cast<const std::function<bool(uint64_t, uint64_t)> *>(user);
+    try { return (*fn)(done, total) ? 0 : 1; } catch (...) { return 1; } // nothing may unwind through the C ABI
+}
 Image Camera::render(const Hittable &world, uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt) const {
     const LoweredScene ls = lower_scene(world);
     const rtmi_scene_desc d = ls.desc();
-    rtmi_scene *scene = nullptr;
-    if (int rc = rtmi_scene_create(&d, opt.device, &scene))
-        throw std::runtime_error(std::string("rtmi_scene_create: ") + rtmi_last_error() + " (code " + std::to_string(rc) + ")");
     rtmi_render_params p{};
     p.nx = nx; p.ny = ny; p.ns = ns; p.max_depth = opt.max_depth; p.t_min = (float)opt.t_min; p.flags = opt.flags;
     p.seed = opt.seed; p.tile_rank = 0; p.tile_world = 1; p.spp_chunks = opt.spp_chunks;
+    if (opt.progress) {
+        p.progress_fn = (uint64_t)(uintptr_t)&progress_trampoline;
+        p.progress_user = (uint64_t)(uintptr_t)&opt.progress;
+    }
     const rtmi_camera c = lower();
     Image img;
     img.nx = nx; img.ny = ny;
     img.linear.resize((size_t)nx * ny * 3);
     img.rgb8.resize((size_t)nx * ny * 3);
+    if (!opt.devices.empty()) { // several GPUs of this process: tiles t % n, one gather (rtmi_render_multi)
+        if (rtmi_render_multi(&d, opt.devices.data(), (uint32_t)opt.devices.size(), &c, &p, img.linear.data(), img.rgb8.data(), &img.stats))
+            throw std::runtime_error(std::string("rtmi_render_multi: ") + rtmi_last_error());
+        return img;
+    }
+    rtmi_scene *scene = nullptr;
+    if (int rc = rtmi_scene_create(&d, opt.device, &scene))
+        throw std::runtime_error(std::string("rtmi_scene_create: ") + rtmi_last_error() + " (code " + std::to_string(rc) + ")");
     const int rc = rtmi_render(scene, &c, &p, img.linear.data(), img.rgb8.data(), nullptr, &img.stats);
     const std::string err = rc ? rtmi_last_error() : "";
     rtmi_scene_destroy(scene);

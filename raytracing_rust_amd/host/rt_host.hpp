@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <map>
+#include <functional>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -319,6 +320,11 @@ Vec3 color(const Ray &ray, const Hittable &world, size_t depth);
 // RTMI_FLAG_SKY in RenderOptions::flags.
 void set_sky_background(bool on);
 bool sky_background();
+// Two more opt-in extensions for the CPU evaluation, off by default (device: RTMI_FLAG_FACE_FORWARD, RTMI_FLAG_UV_BOOK):
+// opaque materials scatter about the normal turned against the ray (the reference never turns it, sphere.rs:50,
+// rect.rs:58-59); get_sphere_uv with the book's pi/2 instead of FRAC_2_PI (sphere.rs:13).
+void set_face_forward(bool on);
+void set_uv_book(bool on);
 
 // ---- lowering to the flat device scene ----------------------------------------------------
 struct LoweredScene {
@@ -374,6 +380,10 @@ struct RenderOptions {
     uint32_t flags = 0;
     uint32_t spp_chunks = 0;
     int device = 0;
+    std::vector<int> devices; // non-empty: render on these GPUs of this process (tiles t % n, one gather); `device` is ignored
+    // Called from the rendering thread about every 50 ms with (work units done, total); return false to cancel.
+    // Replaces the reference's stand-alone bar (src/progressbar.rs:6-58).
+    std::function<bool(uint64_t, uint64_t)> progress;
 };
 struct Image {
     uint32_t nx = 0, ny = 0;

@@ -250,6 +250,25 @@ RTH_API int rth_render_device(void *lowered, void *cam, const rtmi_render_params
         return RTH_OK;
     });
 }
+// overflow report of the asynchronous render calls since the last report (rtmi_scene_status)
+RTH_API int rth_scene_status(void *lowered) {
+    return guard([&] {
+        Obj *o = LOW(lowered);
+        if (!o->dev) throw std::runtime_error("scene not uploaded: call rth_upload first");
+        if (rtmi_scene_status(o->dev, nullptr)) throw std::runtime_error(std::string("rtmi_scene_status: ") + rtmi_last_error());
+        return RTH_OK;
+    });
+}
+// whole image on several GPUs of this process (rtmi_render_multi): uploads the lowered scene to every listed device
+RTH_API int rth_render_multi(void *lowered, void *cam, const rtmi_render_params *p, const int *devices, uint32_t n,
+                             float *out_linear, uint8_t *out_rgb8, rtmi_stats *stats) {
+    return guard([&] {
+        const rtmi_scene_desc d = LOW(lowered)->lowered->desc();
+        const rtmi_camera c = CAM(cam).lower();
+        if (rtmi_render_multi(&d, devices, n, &c, p, out_linear, out_rgb8, stats)) throw std::runtime_error(std::string("rtmi_render_multi: ") + rtmi_last_error());
+        return RTH_OK;
+    });
+}
 // allocate the render buffers for `p` ahead of the first render call (optional)
 RTH_API int rth_render_prepare(void *lowered, const rtmi_render_params *p) {
     return guard([&] {
@@ -340,6 +359,8 @@ RTH_API int rth_get_ray(void *cam, double s, double t, uint64_t seed, double *ou
     });
 }
 RTH_API void rth_set_sky_background(int on) { set_sky_background(on != 0); }
+RTH_API void rth_set_face_forward(int on) { set_face_forward(on != 0); }
+RTH_API void rth_set_uv_book(int on) { set_uv_book(on != 0); }
 // color() of one camera sample on the CPU (f64), same stream layout as the device
 RTH_API int rth_color_sample(void *cam, void *world, uint32_t nx, uint32_t ny, uint32_t i, uint32_t j, uint32_t s,
                              uint64_t seed, double *out3) {

@@ -9,8 +9,13 @@ Every `rng.gen::<f64>()` of the reference builders is replaced by `rng.gen()` on
 explicitly seeded Philox stream (philox.SceneRng, stream_id 2); BVH axes and Perlin
 tables are drawn inside the backend from its own scene stream (stream_id 1), seeded
 with the same scene_seed.  Scenes are reproduced as built by the reference, bugs
-included: nothing here repairs the degenerate light rect of
+included: by default nothing here repairs the degenerate light rect of
 final_scene, the z=0 wall of cornell_smoke or the double floor of cornell_box.
+
+Opt-in extension, never the default: the scene names with the suffix
+"_corrected" build the same scenes with exactly those three slips repaired (the book's
+geometry), so that they render a lit image; everything else — RNG draws, object order —
+is unchanged.  Combine with RTMI_FLAG_FACE_FORWARD / RTMI_FLAG_UV_BOOK for the book's shading.
 """
 import os
 
@@ -106,8 +111,9 @@ def simple_light(api, seed=1):
     return world
 
 
-def cornell_box(api, seed=1):
-    """tests/test.rs:242-323 — two coincident floors at y=0 and no ceiling, as written."""
+def cornell_box(api, seed=1, corrected=False):
+    """tests/test.rs:242-323 — two coincident floors at y=0 and no ceiling, as written (:268-285).
+    corrected=True: the unflipped ZX rect is the ceiling at y=555."""
     api.seed_scene_rng(seed)
     red = api.Lambertian(api.SolidTexture(0.65, 0.05, 0.05))
     white = api.Lambertian(api.SolidTexture(0.73, 0.73, 0.73))
@@ -117,7 +123,8 @@ def cornell_box(api, seed=1):
     world.push(api.FlipNormals(api.Rect(api.PLANE_YZ, 0.0, 0.0, 555.0, 555.0, 555.0, green)))
     world.push(api.Rect(api.PLANE_YZ, 0.0, 0.0, 555.0, 555.0, 0.0, red))
     world.push(api.Rect(api.PLANE_ZX, 227.0, 213.0, 332.0, 343.0, 554.0, light))
-    world.push(api.FlipNormals(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 0.0, white)))
+    # as written: floor twice.  The book: flipped ceiling at 555, plain floor at 0.
+    world.push(api.FlipNormals(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 555.0 if corrected else 0.0, white)))
     world.push(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 0.0, white))
     world.push(api.FlipNormals(api.Rect(api.PLANE_XY, 0.0, 0.0, 555.0, 555.0, 555.0, white)))
     world.push(api.Traslate(api.Rotate(api.AXIS_Y, api.Cube((0.0, 0.0, 0.0), (165.0, 165.0, 165.0), white), -18.0),
@@ -127,8 +134,9 @@ def cornell_box(api, seed=1):
     return world
 
 
-def cornell_smoke(api, seed=1):
-    """tests/test.rs:325-417 — the flipped XY wall sits at k=0 (in front of the camera)."""
+def cornell_smoke(api, seed=1, corrected=False):
+    """tests/test.rs:325-417 — the flipped XY wall sits at k=0, in front of the camera (:369-377).
+    corrected=True: it is the back wall at k=555."""
     api.seed_scene_rng(seed)
     red = api.Lambertian(api.SolidTexture(0.65, 0.05, 0.05))
     white = api.Lambertian(api.SolidTexture(0.73, 0.73, 0.73))
@@ -140,7 +148,7 @@ def cornell_smoke(api, seed=1):
     world.push(api.Rect(api.PLANE_ZX, 127.0, 113.0, 432.0, 443.0, 554.0, light))
     world.push(api.FlipNormals(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 0.0, white)))
     world.push(api.Rect(api.PLANE_ZX, 0.0, 0.0, 555.0, 555.0, 555.0, white))
-    world.push(api.FlipNormals(api.Rect(api.PLANE_XY, 0.0, 0.0, 555.0, 555.0, 0.0, white)))
+    world.push(api.FlipNormals(api.Rect(api.PLANE_XY, 0.0, 0.0, 555.0, 555.0, 555.0 if corrected else 0.0, white)))
     box1 = api.Traslate(api.Rotate(api.AXIS_Y, api.Cube((0.0, 0.0, 0.0), (165.0, 165.0, 165.0), white), -18.0),
                         (130.0, 0.0, 65.0))
     box2 = api.Traslate(api.Rotate(api.AXIS_Y, api.Cube((0.0, 0.0, 0.0), (165.0, 330.0, 165.0), white), 15.0),
@@ -150,8 +158,9 @@ def cornell_smoke(api, seed=1):
     return world
 
 
-def final_scene(api, seed=1):
-    """tests/test.rs:419-523 — the light rect has x0=147 > x1=123 and is never hit."""
+def final_scene(api, seed=1, corrected=False):
+    """tests/test.rs:419-523 — the light rect has x0=147 > x1=123 and is never hit (:444-452).
+    corrected=True: the book's xz_rect(123, 423, 147, 412, 554) in the reference's ZX order (z0, x0, z1, x1)."""
     rng = SceneRng(seed)
     api.seed_scene_rng(seed)
     white = api.Lambertian(api.SolidTexture(0.73, 0.73, 0.73))
@@ -170,7 +179,10 @@ def final_scene(api, seed=1):
             box_list1.append(api.Cube((x0, y0, z0), (x1, y1, z1), ground))
     world.push(api.BVHNode(box_list1, 0.0, 1.0))
     light = api.DiffuseLight(api.SolidTexture(7.0, 7.0, 7.0))
-    world.push(api.Rect(api.PLANE_ZX, 147.0, 412.0, 123.0, 423.0, 554.0, light))
+    if corrected:
+        world.push(api.Rect(api.PLANE_ZX, 147.0, 123.0, 412.0, 423.0, 554.0, light))
+    else:
+        world.push(api.Rect(api.PLANE_ZX, 147.0, 412.0, 123.0, 423.0, 554.0, light))
     center = np.array([400.0, 400.0, 200.0])
     world.push(api.MovingSphere(center, center + np.array([30.0, 0.0, 0.0]), 0.0, 1.0, 50.0,
                                 api.Lambertian(api.SolidTexture(0.7, 0.3, 0.1))))
@@ -205,6 +217,8 @@ SCENES = {
     "cornell_smoke": (cornell_smoke, (278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 40.0),
     "final_scene": (final_scene, (478.0, 278.0, -600.0), (278.0, 278.0, 0.0), 40.0),
 }
+# opt-in corrected variants (see the module docstring); same cameras
+CORRECTED = {"cornell_box", "cornell_smoke", "final_scene"}
 
 
 def set_camera(api, nx, ny, look_from, look_at, view_up=(0.0, 1.0, 0.0), vertical_fov=40.0, focus_dist=10.0,
@@ -216,7 +230,11 @@ def set_camera(api, nx, ny, look_from, look_at, view_up=(0.0, 1.0, 0.0), vertica
 
 def build(api, name, nx, ny, seed=1):
     """Returns (camera, world) for one of the reference's eight test scenes."""
-    fn, look_from, look_at, vfov = SCENES[name]
-    world = fn(api, seed)
+    corrected = name.endswith("_corrected")
+    base = name[:-len("_corrected")] if corrected else name
+    if corrected and base not in CORRECTED:
+        raise KeyError("no corrected variant of scene %r" % base)
+    fn, look_from, look_at, vfov = SCENES[base]
+    world = fn(api, seed, corrected=True) if corrected else fn(api, seed)
     cam = set_camera(api, nx, ny, look_from, look_at, vertical_fov=vfov)
     return cam, world

@@ -91,7 +91,26 @@ def lit_smoke(api, seed=1):
     return world
 
 
+def hollow_glass(api, seed=1):
+    """The hollow-glass idiom: concentric Sphere(r) and Sphere(-0.9 r) — inside BVHs of 2 and of 5 leaves, next to
+    plain neighbours.  Sphere::bounding_box of the negative radius is an inverted box (sphere.rs:79-84); the
+    reference never tests a leaf's box (bvh.rs:72-73), so the inner sphere must stay reachable in every kernel."""
+    api.seed_scene_rng(seed)
+    glass = api.Dielectric(1.5)
+    world = api.HittableList()
+    world.push(api.Sphere((0.0, -1000.0, 0.0), 1000.0, api.Lambertian(api.CheckerTexture(api.SolidTexture(0.2, 0.3, 0.1), api.SolidTexture(0.9, 0.9, 0.9)))))
+    world.push(api.BVHNode([api.Sphere((0.0, 1.0, 0.0), 1.0, glass), api.Sphere((0.0, 1.0, 0.0), -0.9, glass)], 0.0, 1.0))
+    many = [api.Sphere((4.0, 1.0, 0.5), 1.0, glass), api.Sphere((4.0, 1.0, 0.5), -0.95, glass),
+            api.Sphere((-4.0, 1.0, 0.0), 1.0, api.Lambertian(api.SolidTexture(0.4, 0.2, 0.1))),
+            api.Sphere((2.0, 0.5, 2.5), 0.5, api.Metal(api.SolidTexture(0.7, 0.6, 0.5), 0.1)),
+            api.Sphere((2.0, 0.5, 2.5), -0.4, glass)]
+    world.push(api.BVHNode(many, 0.0, 1.0))
+    world.push(api.Sphere((0.0, 9.0, 0.0), 3.0, api.DiffuseLight(api.SolidTexture(6.0, 6.0, 6.0))))
+    return world
+
+
 EXTRA = {
+    "hollow_glass": (hollow_glass, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0),
     "lit_random_spheres": (lit_random_spheres, (13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0),
     "lit_final_scene": (lit_final_scene, (478.0, 278.0, -600.0), (278.0, 278.0, 0.0), 40.0),
     "lit_smoke": (lit_smoke, (278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 40.0),
@@ -99,7 +118,7 @@ EXTRA = {
 
 
 def build(api, name, nx, ny, seed=1):
-    if name in scenes.SCENES:
+    if name in scenes.SCENES or name.endswith("_corrected"):
         return scenes.build(api, name, nx, ny, seed)
     fn, look_from, look_at, vfov = EXTRA[name]
     world = fn(api, seed)

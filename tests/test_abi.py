@@ -87,3 +87,111 @@ def test_no_cpu_fallback_for_rendering(host):
         cam.render(world, 16, 16, 1)
     out = np.zeros(4, np.float32)
     assert abi.load_rtmi().rtmi_probe_math(0, out.ctypes.data, None, out.ctypes.data, 4) == 3  # RTMI_ERR_DEVICE
+
+
+def _desc_with_private_trees(host, name="final_scene"):
+    """A lowered scene's description whose node arrays are private ctypes copies (so a test may corrupt them)."""
+    from raytracing_rust_amd import scenes
+
+    cam, world = scenes.build(host, name, 16, 16, seed=1)
+    sc = host.lower(world)
+    d = sc.desc()
+    nodes = (abi.BvhNode * d.n_nodes)()
+    C.memmove(nodes, d.nodes, C.sizeof(nodes))
+    alt = (abi.Bvh4Node * d.n_alt_nodes)()
+    C.memmove(alt, d.alt_nodes, C.sizeof(alt))
+    d.nodes = C.cast(nodes, C.POINTER(abi.BvhNode))
+    d.alt_nodes = C.cast(alt, C.POINTER(abi.Bvh4Node))
+    return sc, d, nodes, alt  # keep `sc` alive: the other arrays still belong to it
+
+
+def _create_rc(d):
+    lib = abi.load_rtmi()
+    h = C.c_void_p()
+    rc = lib.rtmi_scene_create(C.byref(d), 0, C.byref(h))
+    msg = (lib.rtmi_last_error() or b"").decode()
+    if h.value:
+        lib.rtmi_scene_destroy(h)
+    return rc, msg
+
+
+def test_scene_validation_walks_the_trees(host):
+    """a description arriving through the public ABI is not trusted — cycles (a persistent wavefront
+    would never end), shared subtrees, understated depths (the per-lane LDS stack has the declared number of
+    entries) and mistyped leaves are all rejected before anything reaches the device."""
+    ok_codes = (0, 3)  # 3 = RTMI_ERR_DEVICE on a box without a GPU: validation passed, no device to upload to
+    keep, d, nodes, alt = _desc_with_private_trees(host)
+    rc, msg = _create_rc(d)
+    assert rc in ok_codes, msg
+    root = d.items[0].first
+    assert d.items[0].kind == abi.ITEM_BVH and nodes[root].left >= 0
+
+    # child cycle in the reference tree
+    keep, d, nodes, alt = _desc_with_private_trees(host)
+    inner = nodes[root].left
+    saved = nodes[inner].left
+    nodes[inner].left = root
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "reached twice" in msg
+    nodes[inner].left = saved
+    # shared subtree (two parents, no cycle)
+    nodes[root].right = nodes[root].left
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "reached twice" in msg
+
+    # understated depths
+    keep, d, nodes, alt = _desc_with_private_trees(host)
+    true_depth = d.max_bvh_depth
+    d.max_bvh_depth = true_depth - 1
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "deeper than the declared depth" in msg
+    d.max_bvh_depth = true_depth
+    d.alt_max_depth = d.alt_max_depth - 1
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "alternative tree" in msg and "deeper" in msg
+
+    # alternative tree: cycle, child out of range, leaf naming a primitive of another type / out of range
+    keep, d, nodes, alt = _desc_with_private_trees(host)
+    aroot = d.items[0].alt_first
+    assert aroot >= 0
+    kids = [c for c in alt[aroot].child if 0 <= c < d.n_alt_nodes]
+    assert kids
+    k0 = kids[0]
+    slot = [c for c in range(4) if 0 <= alt[k0].child[c] < d.n_alt_nodes or alt[k0].child[c] < 0][0]
+    saved = alt[k0].child[slot]
+    alt[k0].child[slot] = aroot
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "reached twice" in msg
+    alt[k0].child[slot] = d.n_alt_nodes + 5
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "out of range" in msg
+    alt[k0].child[slot] = C.c_int32(0x80000000 | (abi.PRIM_SPHERE << 28) | 0).value  # primitive 0 is a cube here
+    assert d.prim_meta[0].type == abi.PRIM_CUBE
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "type mismatch" in msg
+    alt[k0].child[slot] = C.c_int32(0x80000000 | (abi.PRIM_CUBE << 28) | (d.n_prims + 7)).value
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "out of range" in msg
+    alt[k0].child[slot] = saved
+    rc, msg = _create_rc(d)
+    assert rc in ok_codes, msg
+
+    # counts without arrays
+    keep, d, nodes, alt = _desc_with_private_trees(host)
+    d.nodes = C.POINTER(abi.BvhNode)()
+    rc, msg = _create_rc(d)
+    assert rc == 1 and "NULL" in msg
+
+
+def test_leaf_boxes_of_negative_radius_spheres_are_proper(host):
+    """the pruned kernels' leaf box of Sphere(c, -r) must be c -+ |r| (+ pad), not the inverted
+    bounding_box() of sphere.rs:79-84 that no ray passes."""
+    import scenes_extra
+
+    cam, world = scenes_extra.build(host, "hollow_glass", 16, 16, seed=1)
+    arr = host.lower(world).arrays()
+    assert len(arr["nodes"]) >= 2
+    for n in arr["nodes"]:
+        for mn, mx, ref in ((n.lmin, n.lmax, n.left), (n.rmin, n.rmax, n.right)):
+            if ref < 0:  # leaf children only: an internal child's box is the reference's own (bvh.rs:60-64), inverted or not
+                assert all(mn[k] < mx[k] for k in range(3)), "inverted leaf box for child %#x" % (ref & 0xffffffff)

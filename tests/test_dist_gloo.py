@@ -88,3 +88,47 @@ def test_every_pixel_has_exactly_one_owner():
         per = [lib.rtmi_local_tiles(C.byref(rdist.rank_params(nx, ny, 1, r, world))) for r in range(world)]
         assert sum(per) == tiles
         assert max(per) - min(per) <= 1  # interleaved: balanced to within one tile
+
+
+def test_bench_self_launches_its_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with WORLD_SIZE unset must itself start N rank processes as fresh
+    children (before any GPU call in the parent) instead of dying on the world-size check.  Without a GPU the
+    ranks stop at their own "needs a GPU" check — which proves they were started with the rank environment."""
+    import subprocess
+
+    if __import__("raytracing_rust_amd").abi.load_rtmi().rtmi_device_count() > 0:
+        pytest.skip("CPU-only check (on a GPU box the ranks would render)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline", "--nx", "64", "--ny", "40", "--spp", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "WORLD_SIZE" not in r.stderr, r.stderr  # the old failure: "--gpus 2 but WORLD_SIZE=1"
+    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr  # both ranks got as far as their own device check
+    assert "rank 0 exited" in r.stderr or "rank 1 exited" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_render_and_gather_on_the_gpu(tmp_path):
+    """N = 2 for real: two processes (gloo, sharing this box's one GPU) each RENDER their tiles on the device, one
+    gather, un-tile on rank 0 — equals the single-process image bit for bit (the CPU test above
+    only fills the framebuffers synthetically)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    ppm = str(tmp_path / "n2.ppm")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-baseline-config", "--scene", "cornell_box", "--nx", "200",
+                        "--ny", "120", "--spp", "8", "--ppm-out", ppm], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["workload"] == "cornell_box 200x120x16spp"
+    sys.path.insert(0, ROOT)
+    from raytracing_rust_amd import Host, abi, ppm_p3, scenes
+
+    host = Host()
+    cam, world = scenes.build(host, "cornell_box", 200, 120, seed=1)
+    one = host.lower(world).render(cam, 200, 120, 16, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+    assert open(ppm, "rb").read() == ppm_p3(one["rgb8"])
+    assert one["rgb8"].max() > 0
