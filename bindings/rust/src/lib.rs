@@ -1,9 +1,19 @@
-//! Safe wrapper over librtmi.so for the reference crate: `Scene` owns the device copy of a lowered world,
-//! `Scene::render` is the triple loop of `create_image` (tests/test.rs:62-79) + `color` (src/color.rs:6-23)
-//! on the MI355X, `ppm_p3` is the text `create_image` returns.  The lowering of the reference's object graph
-//! (`Hittable::lower`) fills a `FlatScene`; it lives in the reference crate because it needs
-//! the concrete types.  UNVERIFIED SOURCE (no Rust toolchain in the build image) — the C++ host mirror
-//! (raytracing_rust_amd/host/rt_host.cpp) is the built and tested implementation of the same calls.
+//! The Rust side of the drop-in boundary for the reference crate (DrStiev/raytracing_rust):
+//!   * `sys`    raw FFI of include/rtmi.h (librtmi.so);
+//!   * `desc`   a plain description of the reference's object graph — what the five-line `describe()` methods that
+//!              INTEGRATION.md adds to the reference's types return (their fields are private to their modules);
+//!   * `lower`  description -> flat scene, the function-by-function counterpart of the C++ SceneBuilder
+//!              (raytracing_rust_amd/host/rt_host.cpp); golden dumps of that lowering: tests/golden/flat_*.bin.gz;
+//!   * `Camera::render`, `create_image` — the triple loop of tests/test.rs:55-85 + `color` (src/color.rs:6-23) on the
+//!     MI355X, one or several GPUs; `Image::to_ppm` is the text `create_image` returns;
+//!   * `philox`, `scenes`, `dump` — seeded scene construction and the byte dump used to diff against the goldens.
+//! UNVERIFIED SOURCE (no Rust toolchain in the build image) — the C++ host mirror is the built and tested
+//! implementation of the same calls.
+pub mod desc;
+pub mod dump;
+pub mod lower;
+pub mod philox;
+pub mod scenes;
 pub mod sys;
 
 use std::ffi::CStr;
@@ -155,4 +165,106 @@ impl Drop for Scene {
     fn drop(&mut self) {
         unsafe { rtmi_scene_destroy(self.raw) }
     }
+}
+
+
+/// `Camera` of src/camera.rs:8-18, with the state `Camera::new` derives (camera.rs:21-51) in f64.
+pub struct Camera {
+    pub origin: [f64; 3],
+    pub lower_left_corner: [f64; 3],
+    pub horizontal: [f64; 3],
+    pub vertical: [f64; 3],
+    pub u: [f64; 3],
+    pub v: [f64; 3],
+    pub time0: f64,
+    pub time1: f64,
+    pub lens_radius: f64,
+}
+
+/// What the reference fixes in code (color.rs:7,9; tests/test.rs:56) plus the device choices.
+pub struct RenderOptions {
+    pub seed: u64,
+    pub max_depth: u32,
+    pub t_min: f64,
+    pub flags: u32,
+    /// empty = `device`; otherwise the GPUs of this process to split the image over (rtmi_render_multi)
+    pub devices: Vec<i32>,
+    pub device: i32,
+    /// called about every 50 ms with (work units done, total); return false to cancel (replaces progressbar.rs)
+    pub progress: Option<Box<dyn FnMut(u64, u64) -> bool>>,
+}
+
+impl Default for RenderOptions {
+    fn default() -> Self {
+        RenderOptions { seed: 42, max_depth: 50, t_min: 0.001, flags: RTMI_FLAG_FAST_CULL, devices: Vec::new(), device: 0, progress: None }
+    }
+}
+
+fn sub(a: [f64; 3], b: [f64; 3]) -> [f64; 3] { [a[0] - b[0], a[1] - b[1], a[2] - b[2]] }
+fn scale(a: [f64; 3], s: f64) -> [f64; 3] { [a[0] * s, a[1] * s, a[2] * s] }
+fn cross(a: [f64; 3], b: [f64; 3]) -> [f64; 3] { [a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]] }
+fn normalize(a: [f64; 3]) -> [f64; 3] { let n = (a[0] * a[0] + a[1] * a[1] + a[2] * a[2]).sqrt(); [a[0] / n, a[1] / n, a[2] / n] }
+
+unsafe extern "C" fn progress_trampoline(done: u64, total: u64, user: *mut std::os::raw::c_void) -> std::os::raw::c_int {
+    let f = &mut *(user as *mut Box<dyn FnMut(u64, u64) -> bool>);
+    // nothing may unwind through the C ABI
+    match std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| f(done, total))) {
+        Ok(true) => 0,
+        _ => 1,
+    }
+}
+
+impl Camera {
+    /// camera.rs:21-51 — note the parameter order (…, vfov, aspect, aperture, focus_dist, t0, t1)
+    #[allow(clippy::too_many_arguments)]
+    pub fn new(look_from: [f64; 3], look_at: [f64; 3], view_up: [f64; 3], vertical_fov: f64, aspect: f64, aperture: f64,
+               focus_dist: f64, time0: f64, time1: f64) -> Camera {
+        let theta = vertical_fov * std::f64::consts::PI / 180.0;
+        let half_height = focus_dist * (theta / 2.0).tan();
+        let half_width = aspect * half_height;
+        let w = normalize(sub(look_from, look_at));
+        let u = normalize(cross(view_up, w));
+        let v = cross(w, u);
+        let llc = sub(sub(sub(look_from, scale(u, half_width)), scale(v, half_height)), scale(w, focus_dist));
+        Camera {
+            origin: look_from, lower_left_corner: llc, horizontal: scale(u, 2.0 * half_width), vertical: scale(v, 2.0 * half_height),
+            u, v, time0, time1, lens_radius: aperture / 2.0,
+        }
+    }
+    /// f64 state rounded ONCE to the device's f32 (arithmetic contract item 4)
+    pub fn lower(&self) -> RtmiCamera {
+        let f = |a: [f64; 3]| [a[0] as f32, a[1] as f32, a[2] as f32];
+        RtmiCamera {
+            origin: f(self.origin), lower_left_corner: f(self.lower_left_corner), horizontal: f(self.horizontal), vertical: f(self.vertical),
+            u: f(self.u), v: f(self.v), time0: self.time0 as f32, time1: self.time1 as f32, lens_radius: self.lens_radius as f32,
+        }
+    }
+    /// The addition the north star asks for: `cam.render(&world, nx, ny, ns)` = lower + upload + the triple loop of
+    /// create_image on the GPU(s) + free.  `world` is what `Hittable::describe()` returns for the reference's world.
+    pub fn render(&self, world: &std::rc::Rc<desc::HittableDesc>, nx: usize, ny: usize, ns: usize, opt: &mut RenderOptions) -> Result<Image, RtmiError> {
+        let flat = lower::lower_world(world).map_err(|e| RtmiError { code: RTMI_ERR_UNSUPPORTED, message: format!("{:?}", e) })?;
+        let mut p = default_params(nx, ny, ns, opt.seed);
+        p.max_depth = opt.max_depth;
+        p.t_min = opt.t_min as f32;
+        p.flags = opt.flags;
+        if let Some(cb) = opt.progress.as_mut() {
+            p.progress_fn = progress_trampoline as usize as u64;
+            p.progress_user = cb as *mut Box<dyn FnMut(u64, u64) -> bool> as usize as u64;
+        }
+        let cam = self.lower();
+        if !opt.devices.is_empty() {
+            let mut img = Image { nx, ny, linear: vec![0.0; nx * ny * 3], rgb8: vec![0; nx * ny * 3], stats: RtmiStats::default() };
+            check(unsafe {
+                rtmi_render_multi(&flat.desc(), opt.devices.as_ptr(), opt.devices.len() as u32, &cam, &p, img.linear.as_mut_ptr(),
+                                  img.rgb8.as_mut_ptr(), &mut img.stats)
+            })?;
+            return Ok(img);
+        }
+        Scene::upload(&flat, opt.device)?.render(&cam, &p)
+    }
+}
+
+/// tests/test.rs:55-85 — `create_image(ny, nx, ns, cam, world) -> String`; note the argument order (ny, nx, …)
+pub fn create_image(ny: usize, nx: usize, ns: usize, cam: &Camera, world: &std::rc::Rc<desc::HittableDesc>) -> Result<String, RtmiError> {
+    Ok(cam.render(world, nx, ny, ns, &mut RenderOptions::default())?.to_ppm())
 }

@@ -1,0 +1,663 @@
+//! Lowering of a described world (`desc::HittableDesc`) to the flat scene of include/rtmi.h — the Rust
+//! counterpart, function by function, of `rt::SceneBuilder` in raytracing_rust_amd/host/rt_host.cpp
+//! (`push_prim`, `true_bounds`, `contained`, `lower_bvh`, `build_alt_tree`, `collapse_alt`, `lower_item`,
+//! `lower_world`).  Same arithmetic (f64 set-up, ONE rounding to f32 at the end), same visiting order, so the flat
+//! arrays are byte-identical to the C++ lowering of the same world: tests/golden/flat_*.bin.gz hold those bytes
+//! (tools/dump_flat_scene.py) and `FlatScene::dump()` writes the same format for a diff on a machine with cargo.
+//! UNVERIFIED SOURCE (no Rust toolchain in the build image).
+use crate::desc::*;
+use crate::sys::*;
+use crate::FlatScene;
+use std::collections::HashMap;
+use std::rc::Rc;
+
+#[derive(Debug)]
+pub enum LowerError {
+    /// the object graph cannot run on the device (rt::Unsupported in the C++ mirror)
+    Unsupported(String),
+    /// where the reference itself panics
+    Panic(String),
+}
+
+const F32_MAX: f32 = 3.402_823_466_385_288_6e38;
+
+fn zero_item() -> RtmiItem {
+    RtmiItem {
+        kind: 0, first: 0, count: 0, flags: 0, xform_first: 0, xform_count: 0, medium_material: 0, neg_inv_density: 0.0,
+        root_min: [0.0; 3], root_max: [0.0; 3], scale: 0.0, alt_first: -1,
+    }
+}
+fn leaf_ref(ty: i32, prim: usize) -> i32 {
+    (0x8000_0000u32 | ((ty as u32) << 28) | prim as u32) as i32 // RTMI_LEAF(type, prim)
+}
+fn put_box(b: &Aabb) -> ([f32; 3], [f32; 3]) {
+    ([b.min[0] as f32, b.min[1] as f32, b.min[2] as f32], [b.max[0] as f32, b.max[1] as f32, b.max[2] as f32])
+}
+fn pad_box(b: &Aabb, pad: f64) -> Aabb {
+    Aabb { min: [b.min[0] - pad, b.min[1] - pad, b.min[2] - pad], max: [b.max[0] + pad, b.max[1] + pad, b.max[2] + pad] }
+}
+
+/// strips FlipNormals wrappers (negation commutes exactly with translation and rotation)
+fn strip_flips<'a>(mut h: &'a Rc<HittableDesc>, flip: &mut bool) -> &'a Rc<HittableDesc> {
+    while let HittableDesc::FlipNormals { inner } = &**h {
+        *flip = !*flip;
+        h = inner;
+    }
+    h
+}
+fn contains_moving(h: &Rc<HittableDesc>) -> bool {
+    let mut dummy = false;
+    match &**strip_flips(h, &mut dummy) {
+        HittableDesc::MovingSphere { .. } => true,
+        HittableDesc::Bvh { left, right, .. } => contains_moving(left) || contains_moving(right),
+        _ => false,
+    }
+}
+fn moving_time_range(h: &Rc<HittableDesc>, lo: &mut f32, hi: &mut f32) {
+    let mut dummy = false;
+    match &**strip_flips(h, &mut dummy) {
+        HittableDesc::MovingSphere { time0, time1, .. } => {
+            *lo = lo.max(time0.min(*time1) as f32);
+            *hi = hi.min(time0.max(*time1) as f32);
+        }
+        HittableDesc::Bvh { left, right, .. } => {
+            moving_time_range(left, lo, hi);
+            moving_time_range(right, lo, hi);
+        }
+        _ => {}
+    }
+}
+/// The geometry's REAL extent (rt_host.cpp true_bounds): Rect on its own plane, spheres with |radius|, a moving
+/// sphere over its own [time0, time1]; None = can never be hit (a rect with x0 > x1, rect.rs:51).
+fn true_bounds(h: &Rc<HittableDesc>) -> Option<Aabb> {
+    let mut dummy = false;
+    match &**strip_flips(h, &mut dummy) {
+        HittableDesc::Rect { plane, x0, y0, x1, y1, k, .. } => {
+            if x0 > x1 || y0 > y1 {
+                return None;
+            }
+            let (kk, a, b) = plane_axes(*plane);
+            let mut out = Aabb { min: [0.0; 3], max: [0.0; 3] };
+            out.min[kk] = *k;
+            out.max[kk] = *k;
+            out.min[a] = *x0;
+            out.max[a] = *x1;
+            out.min[b] = *y0;
+            out.max[b] = *y1;
+            Some(out)
+        }
+        HittableDesc::MovingSphere { center0, center1, radius, .. } => {
+            let r = radius.abs();
+            let b0 = Aabb { min: [center0[0] - r, center0[1] - r, center0[2] - r], max: [center0[0] + r, center0[1] + r, center0[2] + r] };
+            let b1 = Aabb { min: [center1[0] - r, center1[1] - r, center1[2] - r], max: [center1[0] + r, center1[1] + r, center1[2] + r] };
+            Some(surrounding_box(&b0, &b1))
+        }
+        HittableDesc::Sphere { center, radius, .. } => {
+            let r = radius.abs();
+            Some(Aabb { min: [center[0] - r, center[1] - r, center[2] - r], max: [center[0] + r, center[1] + r, center[2] + r] })
+        }
+        other => other.bounding_box(0.0, 1.0), // Cube: exact
+    }
+}
+/// Does every node's box contain the true extent of its subtree (within tol)?  rt_host.cpp contained().
+/// Returns (ok, true bounds of the subtree if it has any).
+fn contained(bvh: &HittableDesc, tol: f64) -> (bool, Option<Aabb>) {
+    let (left, right, bbox) = match bvh {
+        HittableDesc::Bvh { left, right, bbox } => (left, right, bbox),
+        _ => unreachable!(),
+    };
+    let mut ok = true;
+    let mut out: Option<Aabb> = None;
+    for (c, child) in [left, right].iter().enumerate() {
+        if c == 1 && Rc::ptr_eq(left, right) {
+            break;
+        }
+        let mut dummy = false;
+        let h = strip_flips(child, &mut dummy);
+        let tb = if let HittableDesc::Bvh { .. } = &**h {
+            let (sub_ok, sub_tb) = contained(h, tol);
+            ok = sub_ok && ok;
+            sub_tb
+        } else {
+            true_bounds(h)
+        };
+        if let Some(tb) = tb {
+            out = Some(match out {
+                Some(o) => surrounding_box(&o, &tb),
+                None => tb,
+            });
+        }
+    }
+    if let Some(o) = &out {
+        for k in 0..3 {
+            if o.min[k] < bbox.min[k] - tol || o.max[k] > bbox.max[k] + tol {
+                ok = false;
+            }
+        }
+    }
+    (ok, out)
+}
+fn box_area(b: &Aabb) -> f64 {
+    let (dx, dy, dz) = (b.max[0] - b.min[0], b.max[1] - b.min[1], b.max[2] - b.min[2]);
+    2.0 * (dx * dy + dy * dz + dz * dx)
+}
+
+pub struct SceneBuilder {
+    pub out: FlatScene,
+    prim_box: Vec<Option<Aabb>>, // true extent of each primitive that sits in a BVH
+    tex_ids: HashMap<*const TextureDesc, i32>,
+    mat_ids: HashMap<*const MaterialDesc, i32>,
+    run_item: Option<usize>,
+    alt_scratch: Vec<RtmiBvhNode>, // binary SAH tree of the item being lowered
+}
+
+impl SceneBuilder {
+    pub fn new() -> Self {
+        SceneBuilder { out: FlatScene::new(), prim_box: Vec::new(), tex_ids: HashMap::new(), mat_ids: HashMap::new(), run_item: None, alt_scratch: Vec::new() }
+    }
+
+    // ---- textures / materials: one record per distinct object (identity = Rc pointer) ------------------------
+    fn texture_index(&mut self, t: &Rc<TextureDesc>) -> i32 {
+        let key = Rc::as_ptr(t);
+        if let Some(id) = self.tex_ids.get(&key) {
+            return *id;
+        }
+        let mut rec = RtmiTexture { kind: 0, i0: 0, i1: 0, pad: 0, f0: 0.0, f1: 0.0, f2: 0.0, f3: 0.0 };
+        match &**t {
+            TextureDesc::Solid { color } => {
+                rec.kind = RTMI_TEX_SOLID;
+                rec.f0 = color[0] as f32;
+                rec.f1 = color[1] as f32;
+                rec.f2 = color[2] as f32;
+            }
+            TextureDesc::Checker { odd, even } => {
+                rec.kind = RTMI_TEX_CHECKER;
+                rec.i0 = self.texture_index(odd);
+                rec.i1 = self.texture_index(even);
+            }
+            TextureDesc::Noise { noise, scale } => {
+                let mut pn = RtmiPerlin { ranvec: [0.0; 1024], perm: [0; 768] };
+                for i in 0..256 {
+                    pn.ranvec[4 * i] = noise.ran_vec[i][0] as f32;
+                    pn.ranvec[4 * i + 1] = noise.ran_vec[i][1] as f32;
+                    pn.ranvec[4 * i + 2] = noise.ran_vec[i][2] as f32;
+                    pn.perm[i] = noise.perm_x[i] as i32;
+                    pn.perm[256 + i] = noise.perm_y[i] as i32;
+                    pn.perm[512 + i] = noise.perm_z[i] as i32;
+                }
+                self.out.perlin.push(pn);
+                rec.kind = RTMI_TEX_NOISE;
+                rec.i0 = self.out.perlin.len() as i32 - 1;
+                rec.f0 = *scale as f32;
+            }
+            TextureDesc::Image { data, nx, ny } => {
+                assert!(*nx != 0 && *ny != 0 && (*nx as usize) * (*ny as usize) * 3 == data.len(), "ImageTexture: data size != 3*nx*ny");
+                self.out.images.push(RtmiImage { offset: self.out.image_data.len() as u64, nx: *nx, ny: *ny });
+                self.out.image_data.extend_from_slice(data);
+                rec.kind = RTMI_TEX_IMAGE;
+                rec.i0 = self.out.images.len() as i32 - 1;
+            }
+        }
+        self.out.textures.push(rec);
+        let id = self.out.textures.len() as i32 - 1;
+        self.tex_ids.insert(key, id);
+        id
+    }
+    fn texture_needs_uv(&self, tex: i32) -> bool {
+        let t = &self.out.textures[tex as usize];
+        t.kind == RTMI_TEX_IMAGE || (t.kind == RTMI_TEX_CHECKER && (self.texture_needs_uv(t.i0) || self.texture_needs_uv(t.i1)))
+    }
+    fn material_index(&mut self, m: &Rc<MaterialDesc>) -> i32 {
+        let key = Rc::as_ptr(m);
+        if let Some(id) = self.mat_ids.get(&key) {
+            return *id;
+        }
+        let (kind, tex, param): (i32, Option<&Rc<TextureDesc>>, f64) = match &**m {
+            MaterialDesc::Lambertian { albedo } => (RTMI_MAT_LAMBERTIAN, Some(albedo), 0.0),
+            MaterialDesc::Metal { albedo, fuzz } => (RTMI_MAT_METAL, Some(albedo), *fuzz),
+            MaterialDesc::Dielectric { ref_idx } => (RTMI_MAT_DIELECTRIC, None, *ref_idx),
+            MaterialDesc::DiffuseLight { emit } => (RTMI_MAT_DIFFUSE_LIGHT, Some(emit), 0.0),
+            MaterialDesc::Isotropic { albedo } => (RTMI_MAT_ISOTROPIC, Some(albedo), 0.0),
+        };
+        let t = match tex {
+            Some(t) => self.texture_index(t),
+            None => 0,
+        };
+        let flags = if tex.is_some() && self.texture_needs_uv(t) { RTMI_MATFLAG_NEEDS_UV } else { 0 };
+        self.out.materials.push(RtmiMaterial { kind, tex: t, param: param as f32, flags });
+        let id = self.out.materials.len() as i32 - 1;
+        self.mat_ids.insert(key, id);
+        id
+    }
+
+    /// one primitive -> planes A / B + meta (rt_host.cpp push_prim); returns its index
+    fn push_prim(&mut self, h: &HittableDesc, flip: bool, force_moving: bool) -> Result<usize, LowerError> {
+        let (mut a, mut b) = ([0.0f32; 4], [0.0f32; 4]);
+        let mut m = RtmiPrimMeta { material: 0, flags: if flip { RTMI_PRIMFLAG_FLIP } else { 0 }, inv_dt: 0.0, r#type: 0 };
+        match h {
+            HittableDesc::Sphere { center, radius, material } => {
+                a = [center[0] as f32, center[1] as f32, center[2] as f32, *radius as f32];
+                m.material = self.material_index(material);
+                if force_moving {
+                    // c0 + (time - 0) * 1 * 0 == c0 exactly: same bits, one code path inside the BVH
+                    m.r#type = RTMI_PRIM_MSPHERE;
+                    m.inv_dt = 1.0;
+                } else {
+                    m.r#type = RTMI_PRIM_SPHERE;
+                }
+            }
+            HittableDesc::MovingSphere { center0, center1, time0, time1, radius, material } => {
+                let c0 = [center0[0] as f32, center0[1] as f32, center0[2] as f32];
+                let c1 = [center1[0] as f32, center1[1] as f32, center1[2] as f32];
+                let (t0, t1) = (*time0 as f32, *time1 as f32);
+                a = [c0[0], c0[1], c0[2], *radius as f32];
+                b = [c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2], t0];
+                m.inv_dt = 1.0 / (t1 - t0);
+                m.r#type = RTMI_PRIM_MSPHERE;
+                m.material = self.material_index(material);
+            }
+            HittableDesc::Rect { plane, x0, y0, x1, y1, k, material } => {
+                a = [*x0 as f32, *y0 as f32, *x1 as f32, *y1 as f32];
+                b[0] = *k as f32;
+                m.flags |= (*plane as u32) << RTMI_PRIMFLAG_PLANE_SHIFT;
+                m.r#type = RTMI_PRIM_RECT;
+                m.material = self.material_index(material);
+            }
+            HittableDesc::Cube { p_min, p_max, material } => {
+                a = [p_min[0] as f32, p_min[1] as f32, p_min[2] as f32, p_max[0] as f32];
+                b[0] = p_max[1] as f32;
+                b[1] = p_max[2] as f32;
+                m.r#type = RTMI_PRIM_CUBE;
+                m.material = self.material_index(material);
+            }
+            _ => return Err(LowerError::Unsupported("this Hittable cannot be a device primitive (supported: Sphere, MovingSphere, Rect, Cube)".into())),
+        }
+        self.out.prim_a.extend_from_slice(&a);
+        self.out.prim_b.extend_from_slice(&b);
+        self.out.prim_meta.push(m);
+        self.out.prim_gate.extend_from_slice(&[-F32_MAX, -F32_MAX, -F32_MAX, 0.0, F32_MAX, F32_MAX, F32_MAX, 0.0]); // no gate unless a BVH sets one
+        self.prim_box.push(None);
+        Ok(self.out.prim_meta.len() - 1)
+    }
+
+    /// BVHNode -> rtmi_bvh_node records in preorder; leaves appended left to right, so the primitive index is the
+    /// in-order rank the tie rule needs (rt_host.cpp lower_bvh).
+    fn lower_bvh(&mut self, n: &HittableDesc, depth: u32, force_moving: bool, pad: f64, unbounded_leaves: bool) -> Result<i32, LowerError> {
+        let (left, right, bbox) = match n {
+            HittableDesc::Bvh { left, right, bbox } => (left, right, bbox),
+            _ => unreachable!(),
+        };
+        if depth > self.out.max_bvh_depth {
+            self.out.max_bvh_depth = depth;
+        }
+        let id = self.out.nodes.len();
+        self.out.nodes.push(RtmiBvhNode { lmin: [0.0; 3], lmax: [0.0; 3], rmin: [0.0; 3], rmax: [0.0; 3], left: 0, right: 0, pad: [0; 2] });
+        let mut child = [0i32; 2];
+        for c in 0..2 {
+            if c == 1 && Rc::ptr_eq(left, right) {
+                // the same object twice (bvh.rs:44-45)
+                child[1] = child[0];
+                let me = &mut self.out.nodes[id];
+                me.rmin = me.lmin;
+                me.rmax = me.lmax;
+                break;
+            }
+            let mut flip = false;
+            let h = strip_flips(if c == 0 { left } else { right }, &mut flip);
+            let (mn, mx);
+            if let HittableDesc::Bvh { bbox: sub_box, .. } = &**h {
+                if flip {
+                    return Err(LowerError::Unsupported("FlipNormals around a BVHNode inside a BVH is not lowered".into()));
+                }
+                child[c] = self.lower_bvh(h, depth + 1, force_moving, pad, unbounded_leaves)?;
+                let (a, b) = put_box(sub_box);
+                mn = a;
+                mx = b;
+            } else {
+                let prim = self.push_prim(h, flip, force_moving)?;
+                child[c] = leaf_ref(self.out.prim_meta[prim].r#type, prim);
+                // gate = the box of THIS node, the leaf's parent in the reference tree, rounded like every node box
+                let (gmn, gmx) = put_box(bbox);
+                let g = &mut self.out.prim_gate[prim * 8..prim * 8 + 8];
+                g[0] = gmn[0]; g[1] = gmn[1]; g[2] = gmn[2];
+                g[4] = gmx[0]; g[5] = gmx[1]; g[6] = gmx[2];
+                let tb = true_bounds(h);
+                self.prim_box[prim] = tb;
+                // A leaf child has no box test in the reference (bvh.rs:72-73).  The box stored here only serves the
+                // fast-cull prefilter: the primitive's TRUE extent (|radius|) padded by `pad`; unbounded for moving
+                // spheres and for Rect.
+                let big = F32_MAX as f64;
+                let mut lb = Aabb { min: [-big; 3], max: [big; 3] };
+                let plain = !matches!(&**h, HittableDesc::MovingSphere { .. } | HittableDesc::Rect { .. });
+                if !unbounded_leaves && plain {
+                    if let Some(t) = tb {
+                        lb = pad_box(&t, pad);
+                    }
+                }
+                let (a, b) = put_box(&lb);
+                mn = a;
+                mx = b;
+            }
+            let me = &mut self.out.nodes[id];
+            if c == 0 {
+                me.lmin = mn;
+                me.lmax = mx;
+            } else {
+                me.rmin = mn;
+                me.rmax = mx;
+            }
+        }
+        self.out.nodes[id].left = child[0];
+        self.out.nodes[id].right = child[1];
+        Ok(id as i32)
+    }
+
+    /// Binned-SAH tree over the primitives' true extents (rt_host.cpp build_alt_tree).  Returns a child reference
+    /// and the padded box of the subtree.
+    fn build_alt_tree(&mut self, prims: &mut Vec<usize>, lo: usize, hi: usize, depth: u32, pad: f64) -> (i32, Aabb) {
+        let n = hi - lo;
+        if n == 1 {
+            let prim = prims[lo];
+            let b = self.prim_box[prim].unwrap();
+            return (leaf_ref(self.out.prim_meta[prim].r#type, prim), pad_box(&b, pad));
+        }
+        let boxes: Vec<Aabb> = self.prim_box.iter().map(|b| b.unwrap_or(Aabb { min: [0.0; 3], max: [0.0; 3] })).collect();
+        let centroid = |p: usize, a: usize| 0.5 * (boxes[p].min[a] + boxes[p].max[a]);
+        let mut mid = lo + n / 2;
+        let mut split_done = false;
+        if depth < 40 {
+            // SAH split over 16 bins per axis; deeper than that (degenerate inputs) fall back to balanced medians
+            const NB: usize = 16;
+            let mut best_cost = 1e300;
+            let (mut best_axis, mut best_bin) = (-1i32, -1i32);
+            let (mut cmin, mut cmax) = ([1e300f64; 3], [-1e300f64; 3]);
+            for i in lo..hi {
+                for a in 0..3 {
+                    let c = centroid(prims[i], a);
+                    cmin[a] = cmin[a].min(c);
+                    cmax[a] = cmax[a].max(c);
+                }
+            }
+            for a in 0..3 {
+                if !(cmax[a] - cmin[a] > 1e-12) || !(cmax[a] - cmin[a] < 1e30) {
+                    continue;
+                }
+                let mut bb = [Aabb { min: [0.0; 3], max: [0.0; 3] }; NB];
+                let mut cnt = [0usize; NB];
+                let mut used = [false; NB];
+                let scale = NB as f64 / (cmax[a] - cmin[a]);
+                for i in lo..hi {
+                    let mut b = ((centroid(prims[i], a) - cmin[a]) * scale) as i64; // C++ (int): truncation toward zero
+                    b = if b < 0 { 0 } else if b >= NB as i64 { NB as i64 - 1 } else { b };
+                    let b = b as usize;
+                    bb[b] = if used[b] { surrounding_box(&bb[b], &boxes[prims[i]]) } else { boxes[prims[i]] };
+                    used[b] = true;
+                    cnt[b] += 1;
+                }
+                let zero = Aabb { min: [0.0; 3], max: [0.0; 3] };
+                let (mut lbox, mut rbox) = ([zero; NB], [zero; NB]);
+                let (mut lc, mut rc) = ([0usize; NB], [0usize; NB]);
+                let (mut run, mut has, mut acc) = (zero, false, 0usize);
+                for b in 0..NB {
+                    // prefix boxes / counts from the left
+                    if used[b] {
+                        run = if has { surrounding_box(&run, &bb[b]) } else { bb[b] };
+                        has = true;
+                    }
+                    lbox[b] = run;
+                    acc += cnt[b];
+                    lc[b] = acc;
+                }
+                acc = 0;
+                has = false;
+                for b in (0..NB).rev() {
+                    // suffix boxes / counts from the right
+                    if used[b] {
+                        run = if has { surrounding_box(&run, &bb[b]) } else { bb[b] };
+                        has = true;
+                    }
+                    rbox[b] = run;
+                    acc += cnt[b];
+                    rc[b] = acc;
+                }
+                for b in 0..NB - 1 {
+                    if lc[b] == 0 || rc[b + 1] == 0 {
+                        continue;
+                    }
+                    let cost = box_area(&lbox[b]) * lc[b] as f64 + box_area(&rbox[b + 1]) * rc[b + 1] as f64;
+                    if cost < best_cost {
+                        best_cost = cost;
+                        best_axis = a as i32;
+                        best_bin = b as i32;
+                    }
+                }
+            }
+            if best_axis >= 0 {
+                let ax = best_axis as usize;
+                let scale = 16.0 / (cmax[ax] - cmin[ax]);
+                let in_left = |p: usize| {
+                    let mut b = ((centroid(p, ax) - cmin[ax]) * scale) as i64;
+                    b = if b < 0 { 0 } else if b >= 16 { 15 } else { b };
+                    b <= best_bin as i64
+                };
+                // std::stable_partition
+                let seg: Vec<usize> = prims[lo..hi].to_vec();
+                let (l, r): (Vec<usize>, Vec<usize>) = seg.into_iter().partition(|p| in_left(*p));
+                mid = lo + l.len();
+                for (k, p) in l.into_iter().chain(r.into_iter()).enumerate() {
+                    prims[lo + k] = p;
+                }
+                split_done = mid > lo && mid < hi;
+            }
+        }
+        if !split_done {
+            // balanced median split along the widest centroid axis (std::stable_sort)
+            let (mut axis, mut ext) = (0usize, -1.0f64);
+            for a in 0..3 {
+                let (mut mn, mut mx) = (1e300f64, -1e300f64);
+                for i in lo..hi {
+                    let c = centroid(prims[i], a);
+                    mn = mn.min(c);
+                    mx = mx.max(c);
+                }
+                if mx - mn > ext && mx - mn < 1e30 {
+                    ext = mx - mn;
+                    axis = a;
+                }
+            }
+            mid = lo + n / 2;
+            prims[lo..hi].sort_by(|x, y| centroid(*x, axis).partial_cmp(&centroid(*y, axis)).unwrap_or(std::cmp::Ordering::Equal));
+        }
+        let id = self.alt_scratch.len();
+        self.alt_scratch.push(RtmiBvhNode { lmin: [0.0; 3], lmax: [0.0; 3], rmin: [0.0; 3], rmax: [0.0; 3], left: 0, right: 0, pad: [0; 2] });
+        let (l, lb) = self.build_alt_tree(prims, lo, mid, depth + 1, pad);
+        let (r, rb) = self.build_alt_tree(prims, mid, hi, depth + 1, pad);
+        let (lmin, lmax) = put_box(&lb);
+        let (rmin, rmax) = put_box(&rb);
+        let me = &mut self.alt_scratch[id];
+        me.lmin = lmin;
+        me.lmax = lmax;
+        me.rmin = rmin;
+        me.rmax = rmax;
+        me.left = l;
+        me.right = r;
+        (id as i32, surrounding_box(&lb, &rb))
+    }
+
+    /// Binary SAH tree -> 4-wide nodes: a node's children are its grandchildren where the child is an internal
+    /// node, the child itself where it is a leaf (rt_host.cpp collapse_alt).
+    fn collapse_alt(&mut self, r: i32, depth: u32) -> i32 {
+        if r < 0 {
+            return r; // leaf
+        }
+        if depth > self.out.alt_max_depth {
+            self.out.alt_max_depth = depth;
+        }
+        let id = self.out.alt_nodes.len();
+        self.out.alt_nodes.push(RtmiBvh4Node { minx: [0.0; 4], miny: [0.0; 4], minz: [0.0; 4], maxx: [0.0; 4], maxy: [0.0; 4], maxz: [0.0; 4], child: [0; 4], pad: [0; 4] });
+        let b = self.alt_scratch[r as usize];
+        let mut slots: Vec<(i32, [f32; 3], [f32; 3])> = Vec::new();
+        for (ch, mn, mx) in [(b.left, b.lmin, b.lmax), (b.right, b.rmin, b.rmax)] {
+            if ch >= 0 {
+                let g = self.alt_scratch[ch as usize];
+                slots.push((g.left, g.lmin, g.lmax));
+                slots.push((g.right, g.rmin, g.rmax));
+            } else {
+                slots.push((ch, mn, mx));
+            }
+        }
+        let mut me = RtmiBvh4Node { minx: [0.0; 4], miny: [0.0; 4], minz: [0.0; 4], maxx: [0.0; 4], maxy: [0.0; 4], maxz: [0.0; 4], child: [0; 4], pad: [0; 4] };
+        for c in 0..4 {
+            if c < slots.len() {
+                let (rf, mn, mx) = slots[c];
+                me.minx[c] = mn[0]; me.miny[c] = mn[1]; me.minz[c] = mn[2];
+                me.maxx[c] = mx[0]; me.maxy[c] = mx[1]; me.maxz[c] = mx[2];
+                me.child[c] = self.collapse_alt(rf, depth + 1);
+            } else {
+                // empty slot: a box no ray can hit
+                me.minx[c] = F32_MAX; me.miny[c] = F32_MAX; me.minz[c] = F32_MAX;
+                me.maxx[c] = -F32_MAX; me.maxy[c] = -F32_MAX; me.maxz[c] = -F32_MAX;
+                me.child[c] = RTMI_NO_CHILD;
+            }
+        }
+        self.out.alt_nodes[id] = me;
+        id as i32
+    }
+
+    /// one entry of the world list: [FlipNormals][ConstantMedium][Traslate/Rotate chain] geometry
+    fn lower_item(&mut self, top: &Rc<HittableDesc>) -> Result<(), LowerError> {
+        let mut it = zero_item();
+        it.xform_first = self.out.xforms.len() as i32;
+        let (mut flip, mut medium) = (false, false);
+        let mut h = top;
+        loop {
+            // peel wrappers, outermost first
+            match &**h {
+                HittableDesc::FlipNormals { inner } => {
+                    flip = !flip;
+                    h = inner;
+                }
+                HittableDesc::ConstantMedium { boundary, density, phase } => {
+                    if medium {
+                        return Err(LowerError::Unsupported("nested ConstantMedium is not lowered".into()));
+                    }
+                    if it.xform_count > 0 {
+                        return Err(LowerError::Unsupported("ConstantMedium inside Traslate/Rotate is not lowered".into()));
+                    }
+                    medium = true;
+                    it.medium_material = self.material_index(phase);
+                    it.neg_inv_density = -(1.0f32 / (*density as f32));
+                    h = boundary;
+                }
+                HittableDesc::Traslate { inner, offset } => {
+                    self.out.xforms.push(RtmiXform { kind: RTMI_XF_TRANSLATE, x: offset[0] as f32, y: offset[1] as f32, z: offset[2] as f32 });
+                    it.xform_count += 1;
+                    h = inner;
+                }
+                HittableDesc::Rotate { axis, inner, sin_theta, cos_theta } => {
+                    self.out.xforms.push(RtmiXform { kind: RTMI_XF_ROTATE_X + *axis as i32, x: *sin_theta as f32, y: *cos_theta as f32, z: 0.0 });
+                    it.xform_count += 1;
+                    h = inner;
+                }
+                _ => break,
+            }
+        }
+        it.flags = (if flip { RTMI_ITEMFLAG_FLIP } else { 0 }) | (if medium { RTMI_ITEMFLAG_MEDIUM } else { 0 });
+        match &**h {
+            HittableDesc::Bvh { bbox, .. } => {
+                it.kind = RTMI_ITEM_BVH;
+                let (mn, mx) = put_box(bbox);
+                it.root_min = mn;
+                it.root_max = mx;
+                let mut scale = 0.0f64;
+                for k in 0..3 {
+                    scale = scale.max(bbox.min[k].abs().max(bbox.max[k].abs()));
+                }
+                if !(scale < 1e30) {
+                    scale = 1e30;
+                }
+                let (prunable, _) = contained(h, scale / 65536.0);
+                it.scale = if prunable { scale as f32 } else { 1e30 }; // 1e30: the pruning margin swallows every distance
+                let prim_begin = self.out.prim_meta.len();
+                it.first = self.lower_bvh(h, 1, contains_moving(h), scale / 8192.0, !prunable)?;
+                let (mut lo, mut hi) = (self.out.bvh_time_lo, self.out.bvh_time_hi);
+                moving_time_range(h, &mut lo, &mut hi);
+                self.out.bvh_time_lo = lo;
+                self.out.bvh_time_hi = hi;
+                if prunable {
+                    // alternative (SAH) tree over the same primitives, traversed by the cooperative kernel
+                    let mut prims: Vec<usize> = (prim_begin..self.out.prim_meta.len()).filter(|q| self.prim_box[*q].is_some()).collect();
+                    if prims.len() >= 2 {
+                        self.alt_scratch.clear();
+                        let n = prims.len();
+                        let (broot, _) = self.build_alt_tree(&mut prims, 0, n, 1, scale / 8192.0);
+                        it.alt_first = self.collapse_alt(broot, 1);
+                    }
+                }
+            }
+            HittableDesc::List { list } => {
+                it.kind = RTMI_ITEM_LIST;
+                it.first = self.out.prim_meta.len() as i32;
+                for e in list {
+                    let mut f2 = false;
+                    let p = strip_flips(e, &mut f2);
+                    self.push_prim(p, f2, false)?;
+                    it.count += 1;
+                }
+            }
+            prim => {
+                // A run of consecutive plain primitives of the world list (no transform, no medium) becomes ONE list
+                // item: scanned in order with the shrinking t_max exactly as items are (hittable.rs:37-47).
+                if !medium && it.xform_count == 0 {
+                    if let Some(ri) = self.run_item {
+                        let (first, count) = (self.out.items[ri].first, self.out.items[ri].count);
+                        if (first + count) as usize == self.out.prim_meta.len() {
+                            self.push_prim(prim, flip, false)?;
+                            self.out.items[ri].count += 1;
+                            return Ok(());
+                        }
+                    }
+                    it.kind = RTMI_ITEM_LIST;
+                    it.flags = 0;
+                    it.first = self.push_prim(prim, flip, false)? as i32;
+                    it.count = 1;
+                    self.out.items.push(it);
+                    self.run_item = Some(self.out.items.len() - 1);
+                    return Ok(());
+                }
+                it.kind = RTMI_ITEM_LIST;
+                it.first = self.push_prim(prim, false, false)? as i32;
+                it.count = 1;
+            }
+        }
+        self.run_item = None;
+        self.out.items.push(it);
+        Ok(())
+    }
+
+    /// world.hit(ray, 0.001, MAX) on a HittableList == the scan the device performs over items; any other world is
+    /// a list of one
+    pub fn lower_world(&mut self, world: &Rc<HittableDesc>) -> Result<(), LowerError> {
+        if let HittableDesc::List { list } = &**world {
+            if list.is_empty() {
+                return Err(LowerError::Unsupported("empty world".into()));
+            }
+            for e in list {
+                self.lower_item(e)?;
+            }
+        } else {
+            self.lower_item(world)?;
+        }
+        if self.out.max_bvh_depth > RTMI_MAX_BVH_DEPTH {
+            return Err(LowerError::Unsupported("BVH deeper than RTMI_MAX_BVH_DEPTH".into()));
+        }
+        Ok(())
+    }
+}
+
+/// `lower_scene(world)` of INTEGRATION.md
+pub fn lower_world(world: &Rc<HittableDesc>) -> Result<FlatScene, LowerError> {
+    let mut b = SceneBuilder::new();
+    b.lower_world(world)?;
+    Ok(b.out)
+}

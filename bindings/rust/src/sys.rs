@@ -1,4 +1,4 @@
-//! Raw FFI of include/rtmi.h (ABI version 2): one declaration per entry point, one `#[repr(C)]` struct per
+//! Raw FFI of include/rtmi.h (ABI version 5): one declaration per entry point, one `#[repr(C)]` struct per
 //! C struct, same field order.  UNVERIFIED SOURCE: the build image has no Rust toolchain; the layouts are
 //! kept in sync with the tested ctypes binding (raytracing_rust_amd/abi.py) by tests/test_rust_binding_source.py.
 #![allow(non_camel_case_types)]
@@ -21,6 +21,33 @@ pub const RTMI_ERR_DEVICE: i32 = 3;
 pub const RTMI_ERR_NOMEM: i32 = 4;
 pub const RTMI_ERR_CANCELLED: i32 = 5;
 pub const RTMI_TEXEL_POISON: u32 = 0x8000_0000;
+pub const RTMI_MAX_BVH_DEPTH: u32 = 24;
+pub const RTMI_TILE: u32 = 8;
+pub const RTMI_TEX_SOLID: i32 = 0;
+pub const RTMI_TEX_CHECKER: i32 = 1;
+pub const RTMI_TEX_NOISE: i32 = 2;
+pub const RTMI_TEX_IMAGE: i32 = 3;
+pub const RTMI_MAT_LAMBERTIAN: i32 = 0;
+pub const RTMI_MAT_METAL: i32 = 1;
+pub const RTMI_MAT_DIELECTRIC: i32 = 2;
+pub const RTMI_MAT_DIFFUSE_LIGHT: i32 = 3;
+pub const RTMI_MAT_ISOTROPIC: i32 = 4;
+pub const RTMI_MATFLAG_NEEDS_UV: u32 = 1;
+pub const RTMI_PRIM_SPHERE: i32 = 0;
+pub const RTMI_PRIM_MSPHERE: i32 = 1;
+pub const RTMI_PRIM_RECT: i32 = 2;
+pub const RTMI_PRIM_CUBE: i32 = 3;
+pub const RTMI_PRIMFLAG_FLIP: u32 = 1;
+pub const RTMI_PRIMFLAG_PLANE_SHIFT: u32 = 8;
+pub const RTMI_XF_TRANSLATE: i32 = 0;
+pub const RTMI_XF_ROTATE_X: i32 = 1;
+pub const RTMI_XF_ROTATE_Y: i32 = 2;
+pub const RTMI_XF_ROTATE_Z: i32 = 3;
+pub const RTMI_ITEM_LIST: i32 = 0;
+pub const RTMI_ITEM_BVH: i32 = 1;
+pub const RTMI_ITEMFLAG_FLIP: u32 = 1;
+pub const RTMI_ITEMFLAG_MEDIUM: u32 = 2;
+pub const RTMI_NO_CHILD: i32 = 0x7fff_ffff;
 
 #[repr(C)]
 #[derive(Clone, Copy)]

@@ -47,8 +47,10 @@ def build_rtmi(force=False, verbose=False):
     # operand selection wrong in at least one place (hit point/normal of a sphere under Rotate about Z: every
     # pixel differed from the oracle, found by tests/test_random_scenes.py; fine with the function out of line,
     # fine without SLP).  The scalar code is also 2-3 % faster on this VALU-bound path.
+    # RTMI_EXTRA_CFLAGS: experiment switches (-DRTMI_...) for A/B builds into another RTMI_LIB_DIR (tools/ab_build.sh)
+    extra = os.environ.get("RTMI_EXTRA_CFLAGS", "").split()
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-std=c++17", "-I" + INCLUDE, "-o", LIBRTMI] + RTMI_SRC
+           "-std=c++17", "-I" + INCLUDE] + extra + ["-o", LIBRTMI] + RTMI_SRC
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.run(cmd, check=True)

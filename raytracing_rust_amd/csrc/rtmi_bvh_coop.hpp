@@ -196,7 +196,13 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
                 } else if (vl) { cur = left; tent = tl; }
                 else if (vr) { cur = right; tent = tr; }
                 else cur = COOP_NONE;
-            } else { // leaf
+            }
+        }
+        // Leaf part, after the node part instead of beside it: a worker whose visit just kept a LEAF as its nearest
+        // child tests it in this same round (the leaf code runs for the workers that popped a leaf anyway), which
+        // takes one pop round off every chain (measured: final_scene +3.3 %, random_spheres +8 %).
+        if (cur != COOP_NONE && (cur & (1u << 25))) {
+            {
                 const int type = (int)((cur >> 22) & 7u);
                 const int idx = (int)(cur & 0x003fffffu);
                 float t;

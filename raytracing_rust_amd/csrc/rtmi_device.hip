@@ -163,7 +163,9 @@ static int validate(const rtmi_scene_desc *d) {
             } else {
                 const int32_t l = d->nodes[n].left, r = d->nodes[n].right;
                 if (l >= 0) todo.emplace_back((uint32_t)l, depth + 1u);
-                if (r >= 0) todo.emplace_back((uint32_t)r, depth + 1u); // an internal child listed twice is caught by `seen`
+                // right == left is legal: BVHNode::new over ONE element stores it on both sides (bvh.rs:44-45); the
+                // kernels visit it once.  Any other repeated reference is caught by `seen`.
+                if (r >= 0 && r != l) todo.emplace_back((uint32_t)r, depth + 1u);
             }
         }
         return RTMI_OK;

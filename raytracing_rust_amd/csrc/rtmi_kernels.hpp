@@ -112,10 +112,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
         // ================= phase B: shade every lane that holds a hit =================
         if (__ballot(have_hit) == 0ull) break; // nobody holds a hit and nobody can trace: all done
         prof_tick<PROF>(prof, 16, have_hit);
-        if (have_hit) {
+        {
+            const bool shading = have_hit;
             have_hit = false;
-            if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
-            if (!shade_hit(sc, P.max_depth, P.ext, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+            if (SIG && shading) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+            // all lanes call (wavefront texture lookup); the traversal stacks are idle now: LDS scratch
+            const bool goes_on = shade_hit(sc, P.max_depth, P.ext, g, k0, k1, shading, closest, best_item, best_pf, best_medium, pa,
+                                           reinterpret_cast<float *>(&lds_stack[wave][0][0][0]));
+            if (shading && !goes_on) {
                 // absorbed, emitter or depth limit: the path ends
                 path_end(P, oidx, pa);
                 if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
@@ -244,10 +248,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
         // ================= phase B =================
         if (__ballot(have_hit) == 0ull) break;
         prof_tick<PROF>(prof, 16, have_hit);
-        if (have_hit) {
+        {
+            const bool shading = have_hit;
             have_hit = false;
-            if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
-            if (!shade_hit(sc, P.max_depth, P.ext, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+            if (SIG && shading) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+            // all lanes call (wavefront texture lookup); the traversal pool is idle now: LDS scratch
+            const bool goes_on = shade_hit(sc, P.max_depth, P.ext, g, k0, k1, shading, closest, best_item, best_pf, best_medium, pa,
+                                           reinterpret_cast<float *>(cw.wlds));
+            if (shading && !goes_on) {
                 path_end(P, oidx, pa);
                 if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
                 alive = false;
@@ -495,9 +503,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                 }
             }
         } else if (run == ST_SHADE) {
-            if (st == ST_SHADE) {
-                if (SIG) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
-                if (shade_hit(sc, P.max_depth, P.ext, g, k0, k1, closest, best_item, best_pf, best_medium, pa)) {
+            const bool shading = st == ST_SHADE;
+            if (SIG && shading) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+            // all lanes call (wavefront texture lookup).  Scratch = entry 0 of the traversal stacks of all lanes: the
+            // lanes in ST_NODE / ST_PRIM hold live entries there, so the 64 words are saved around the call.
+            const uint32_t saved0 = stack[0];
+            const bool goes_on = shade_hit(sc, P.max_depth, P.ext, g, k0, k1, shading, closest, best_item, best_pf, best_medium, pa,
+                                           reinterpret_cast<float *>(stack - lane));
+            stack[0] = saved0;
+            if (shading) {
+                if (goes_on) {
                     W.o = pa.ro; W.d = pa.rd;
                     ray_derive(W);
                     it = 0; ph = 0; pending = false; closest = RTMI_FLT_MAX; best_item = -1; best_medium = false;

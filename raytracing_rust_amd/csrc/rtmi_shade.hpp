@@ -13,6 +13,14 @@ __device__ __forceinline__ uint32_t as_usize_u32(float x) { // Rust `as usize`, 
     if (x >= 4294967296.0f) return 0u; // fp32 values >= 2^32 are multiples of 512: low 8 bits are 0
     return (uint32_t)x;
 }
+// ImageTexture's `(x) as usize` followed by the clamp to n - 1 (texture.rs:91-101): Rust's cast saturates, so any
+// x >= n — including +inf and values beyond 2^32, where as_usize_u32's wrap to 0 would pick the FIRST texel — lands
+// on n - 1; negative and NaN give 0.
+__device__ __forceinline__ uint32_t as_image_index(float x, uint32_t n) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= (float)n) return n - 1u;
+    return (uint32_t)x;
+}
 // Perlin::noise + perlin_interpolation — perlin.rs:76-97, 38-56
 __device__ __forceinline__ float perlin_noise(const rtmi_perlin *pn, F3 p) {
     const float fx = __builtin_floorf(p.x), fy = __builtin_floorf(p.y), fz = __builtin_floorf(p.z);
@@ -51,27 +59,115 @@ __device__ __forceinline__ float perlin_turb(const rtmi_perlin *pn, F3 p, int de
     }
     return __builtin_fabsf(accum);
 }
-// Texture::value — texture.rs:21-25 (Solid), :39-48 (Checker), :65-71 (Noise), :86-108 (Image)
-__device__ __forceinline__ F3 tex_value(const DevScene &sc, int tex, float u, float v, F3 p) {
-    rtmi_texture t = sc.texs[tex];
-    for (int guard = 0; guard < 16 && t.kind == RTMI_TEX_CHECKER; guard++) {
-        const float s = rtmi_sinf(10.0f * p.x) * rtmi_sinf(10.0f * p.y) * rtmi_sinf(10.0f * p.z);
-        t = sc.texs[s < 0.0f ? t.i0 : t.i1];
+// One corner term of Perlin::noise for octave point tp (perlin.rs:38-56, 76-97), as perlin_noise evaluates it: the
+// cooperative turbulence below computes the 56 terms of a turb(p, 7) on 56 lanes with the same operations.
+__device__ __forceinline__ float perlin_corner_term(const rtmi_perlin *pn, F3 tp, int di, int dj, int dk) {
+    const float fx = __builtin_floorf(tp.x), fy = __builtin_floorf(tp.y), fz = __builtin_floorf(tp.z);
+    const float u = tp.x - fx, v = tp.y - fy, w = tp.z - fz;
+    const uint32_t i = as_usize_u32(fx), j = as_usize_u32(fy), k = as_usize_u32(fz);
+    const float uu = u * u * (3.0f - 2.0f * u);
+    const float vv = v * v * (3.0f - 2.0f * v);
+    const float ww = w * w * (3.0f - 2.0f * w);
+    const float4 *rv = reinterpret_cast<const float4 *>(pn->ranvec);
+    const int h = pn->perm[(i + (uint32_t)di) & 255u] ^ pn->perm[256 + ((j + (uint32_t)dj) & 255u)] ^
+                  pn->perm[512 + ((k + (uint32_t)dk) & 255u)];
+    const float4 c = rv[h];
+    const float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
+    const float fi = di ? uu : (1.0f - uu);
+    const float fj = dj ? vv : (1.0f - vv);
+    const float fk = dk ? ww : (1.0f - ww);
+    return fi * fj * fk * (c.x * wx + c.y * wy + c.z * wz);
+}
+// Perlin::turb(p, 7) of ONE point for the whole wavefront (every lane calls it with the same pn and p; every lane
+// receives the value).  Lane 8*o + c evaluates corner c of octave o (tp = p * 2^o: the repeated doubling of
+// perlin.rs:107 is exact), lanes 0..6 add the eight terms of their octave in the reference's order (di, dj, dk
+// ascending, starting from 0.0), and the octaves are combined in order with the weights 1, 1/2, ... — the same
+// operations on the same values as perlin_turb, so the same bits; 2 dependent table look-ups instead of 14.
+// `scratch`: 64 floats of LDS private to the wavefront.
+__device__ __forceinline__ float perlin_turb7_wave(const rtmi_perlin *pn, F3 p, float *scratch) {
+    const int lane = threadIdx.x & 63;
+    const int o = lane >> 3, c = lane & 7;
+    float term = 0.0f;
+    if (lane < 56) {
+        const float s = (float)(1u << o);
+        term = perlin_corner_term(pn, f3(p.x * s, p.y * s, p.z * s), (c >> 2) & 1, (c >> 1) & 1, c & 1);
     }
-    if (t.kind == RTMI_TEX_NOISE) {
-        const float g = 0.5f * (1.0f + rtmi_sinf(t.f0 * p.x + 5.0f * perlin_turb(sc.perlin + t.i0, p, 7)));
-        return f3(g, g, g);
+    scratch[lane] = term;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float oct = 0.0f;
+    if (lane < 7) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) oct += scratch[lane * 8 + k];
     }
-    if (t.kind == RTMI_TEX_IMAGE) {
-        const rtmi_image im = sc.images[t.i0];
-        uint32_t i = as_usize_u32(u * (float)im.nx);
-        uint32_t j = as_usize_u32((1.0f - v) * (float)im.ny);
-        if (i > im.nx - 1) i = im.nx - 1;
-        if (j > im.ny - 1) j = im.ny - 1;
-        const uint8_t *px = sc.image_data + im.offset + 3ull * i + 3ull * im.nx * j;
-        return f3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+    float accum = 0.0f, weight = 1.0f;
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        accum += weight * __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(oct), i));
+        weight *= 0.5f;
     }
-    return f3(t.f0, t.f1, t.f2);
+    __builtin_amdgcn_wave_barrier(); // scratch may be rewritten by the next call
+    return __builtin_fabsf(accum);
+}
+#ifndef RTMI_COOP_NOISE_MAX
+#define RTMI_COOP_NOISE_MAX 10 // more lanes than this want turbulence at once: every lane evaluates its own (cheaper)
+#endif
+// Texture::value — texture.rs:21-25 (Solid), :39-48 (Checker), :65-71 (Noise), :86-108 (Image) — for the whole
+// wavefront: ALL 64 lanes call it, lanes with want = true receive their value.  Perlin turbulence (7 octaves x 8
+// corners, two dependent table look-ups each: ~1700 instructions and 14 memory latencies per lane) is what a few
+// lanes of a shading batch need while the others wait, so those few points are evaluated one after the other by
+// all 64 lanes together (perlin_turb7_wave); measured on final_scene: Perlin cost 4.3 % of the frame.
+__device__ __forceinline__ F3 tex_value_wave(const DevScene &sc, bool want, int tex, float u, float v, F3 p, float *scratch) {
+    F3 out = f3(1, 1, 1);
+    bool noise = false;
+    int table = 0;
+    float nscale = 0.0f;
+    if (want) {
+        rtmi_texture t = sc.texs[tex];
+        for (int guard = 0; guard < 16 && t.kind == RTMI_TEX_CHECKER; guard++) {
+            const float s = rtmi_sinf(10.0f * p.x) * rtmi_sinf(10.0f * p.y) * rtmi_sinf(10.0f * p.z);
+            t = sc.texs[s < 0.0f ? t.i0 : t.i1];
+        }
+        if (t.kind == RTMI_TEX_NOISE) {
+            noise = true; table = t.i0; nscale = t.f0;
+        } else if (t.kind == RTMI_TEX_IMAGE) {
+            const rtmi_image im = sc.images[t.i0];
+            uint32_t i = as_image_index(u * (float)im.nx, im.nx);
+            uint32_t j = as_image_index((1.0f - v) * (float)im.ny, im.ny);
+            const uint8_t *px = sc.image_data + im.offset + 3ull * i + 3ull * im.nx * j;
+            out = f3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+        } else {
+            out = f3(t.f0, t.f1, t.f2);
+        }
+    }
+    unsigned long long m = __ballot(noise);
+    if (m != 0ull) { // wave-uniform
+        float turb = 0.0f;
+#ifdef RTMI_DIAG_NO_NOISE // measurement only (wrong image): what does Perlin turbulence cost?
+        turb = 0.5f;
+#else
+        if (__popcll(m) > RTMI_COOP_NOISE_MAX) {
+            if (noise) turb = perlin_turb(sc.perlin + table, p, 7);
+        } else {
+            const int lane = threadIdx.x & 63;
+            while (m != 0ull) { // wave-uniform loop over the lanes that want turbulence
+                const int L = (int)__ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const F3 q = f3(__uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.x), L)),
+                                __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.y), L)),
+                                __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(p.z), L)));
+                const int tab = __builtin_amdgcn_readlane(table, L);
+                const float r = perlin_turb7_wave(sc.perlin + tab, q, scratch);
+                if (lane == L) turb = r;
+            }
+        }
+#endif
+        if (noise) {
+            const float g = 0.5f * (1.0f + rtmi_sinf(nscale * p.x + 5.0f * turb));
+            out = f3(g, g, g);
+        }
+    }
+    return out;
 }
 
 // get_sphere_uv — sphere.rs:9-15 (FRAC_2_PI, sic)
@@ -177,122 +273,132 @@ __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, f
 
 // HitRecord of the closest hit (hittable.rs:9-16), built once, then
 // color(): emitted + attenuation * color(scattered) — color.rs:8-15, in throughput form.
-// Returns true when the path continues (pa holds the scattered ray), false when it ended.
+// ALL 64 lanes call this together (the texture lookup is a wavefront operation, tex_value_wave); lanes with
+// active = true hold a hit to shade.  Returns true when the lane's path continues (pa holds the scattered ray),
+// false when it ended (or the lane was not active).  `scratch`: 64 floats of LDS private to the wavefront.
 __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth, uint32_t ext, Rng &g, uint32_t k0, uint32_t k1,
-                                          float closest, int best_item, int best_pf, bool best_medium, Path &pa) {
-    const rtmi_item I = sc.items[best_item];
-    F3 hp, hn;
+                                          bool active, float closest, int best_item, int best_pf, bool best_medium, Path &pa,
+                                          float *scratch) {
+    F3 hp = f3(0, 0, 0), hn = f3(1, 0, 0);
     float hu = 0.0f, hv = 0.0f;
-    int mat_idx;
-    if (best_medium) {
-        hp = pa.ro + pa.rd * closest;      // ray.pointing_at(t) — medium.rs:47
-        hn = f3(1.0f, 0.0f, 0.0f);         // medium.rs:48
-        mat_idx = I.medium_material;
-    } else {
-        F3 lo = pa.ro, ld = pa.rd;
-        if (I.xform_count > 0) xform_ray(sc.xforms, I.xform_first, I.xform_count, lo, ld);
-        const int idx = best_pf >> 3, face = best_pf & 7;
-        const rtmi_prim_meta M = sc.meta[idx];
-        const float4 A = sc.prim_a[idx];
-        mat_idx = M.material;
-        const bool needs_uv = (sc.mats[mat_idx].flags & RTMI_MATFLAG_NEEDS_UV) != 0u;
-        hp = lo + ld * closest; // ray.pointing_at(t)
-        if (M.type == RTMI_PRIM_SPHERE || M.type == RTMI_PRIM_MSPHERE) {
-            F3 c = f3(A.x, A.y, A.z);
-            if (M.type == RTMI_PRIM_MSPHERE) c = moving_center(A, sc.prim_b[idx], M.inv_dt, pa.rtime);
-            hn = vdiv(hp - c, A.w); // sphere.rs:50 — outward, never face-forwarded
-            if (needs_uv) sphere_uv(hn, (ext & RTMI_EXT_UV_BOOK) != 0u, hu, hv);
-        } else {
-            int plane;
-            float x0, y0, x1, y1;
-            if (M.type == RTMI_PRIM_RECT) {
-                plane = (int)((M.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
-                x0 = A.x; y0 = A.y; x1 = A.z; y1 = A.w;
-            } else { // cube face -> its rect (cube.rs:21-74)
-                const float4 B = sc.prim_b[idx];
-                const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
-                if (face < 2) { plane = 2; x0 = ax; y0 = ay; x1 = bx; y1 = by; }
-                else if (face < 4) { plane = 1; x0 = az; y0 = ax; x1 = bz; y1 = bx; }
-                else { plane = 0; x0 = ay; y0 = az; x1 = by; y1 = bz; }
-            }
-            hn = f3(plane == 0 ? 1.0f : 0.0f, plane == 1 ? 1.0f : 0.0f, plane == 2 ? 1.0f : 0.0f); // rect.rs:58-59
-            if (needs_uv) { // rect.rs:52-56
-                const float x = plane == 0 ? lo.y + closest * ld.y : (plane == 1 ? lo.z + closest * ld.z : lo.x + closest * ld.x);
-                const float y = plane == 0 ? lo.z + closest * ld.z : (plane == 1 ? lo.x + closest * ld.x : lo.y + closest * ld.y);
-                hu = (x - x0) / (x1 - x0);
-                hv = (y - y0) / (y1 - y0);
-            }
-        }
-        if (I.xform_count > 0) xform_hit(sc.xforms, I.xform_first, I.xform_count, hp, hn);
-        if (((M.flags ^ I.flags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
-    }
-
-    // Material::emitted / Material::scatter (material.rs).  The rejection sampler and the texture
-    // lookup are needed by several materials; they are evaluated ONCE here for all lanes that need
-    // them (a per-material copy would run the same long code serially for each lane subset).  The
-    // draw order per lane is unchanged: Lambertian/Isotropic/fuzzy Metal draw only inside the sampler,
-    // Dielectric draws its single uniform, DiffuseLight draws nothing.
-    const rtmi_material M = sc.mats[mat_idx];
-    const int kind = M.kind;
-    const bool can_scatter = pa.depth < max_depth; // color.rs:9
-    const bool textured = kind == RTMI_MAT_LAMBERTIAN || kind == RTMI_MAT_METAL || kind == RTMI_MAT_ISOTROPIC;
-    const bool want_sample = can_scatter && (kind == RTMI_MAT_LAMBERTIAN || kind == RTMI_MAT_ISOTROPIC ||
-                                             (kind == RTMI_MAT_METAL && M.param > 0.0f));
+    rtmi_material M;
+    M.kind = -1; M.tex = 0; M.param = 0.0f; M.flags = 0u;
+    bool can_scatter = false, textured = false;
     F3 rs = f3(0, 0, 0);
-    if (want_sample) rs = random_in_unit_sphere(g, k0, k1);
-    F3 tv = f3(1, 1, 1);
-    if (kind == RTMI_MAT_DIFFUSE_LIGHT || (can_scatter && textured)) tv = tex_value(sc, M.tex, hu, hv, hp);
-    if (kind == RTMI_MAT_DIFFUSE_LIGHT) pa.L = pa.L + pa.T * tv; // material.rs:148-150
+    if (active) {
+        const rtmi_item I = sc.items[best_item];
+        int mat_idx;
+        if (best_medium) {
+            hp = pa.ro + pa.rd * closest;      // ray.pointing_at(t) — medium.rs:47
+            hn = f3(1.0f, 0.0f, 0.0f);         // medium.rs:48
+            mat_idx = I.medium_material;
+        } else {
+            F3 lo = pa.ro, ld = pa.rd;
+            if (I.xform_count > 0) xform_ray(sc.xforms, I.xform_first, I.xform_count, lo, ld);
+            const int idx = best_pf >> 3, face = best_pf & 7;
+            const rtmi_prim_meta PM = sc.meta[idx];
+            const float4 A = sc.prim_a[idx];
+            mat_idx = PM.material;
+            const bool needs_uv = (sc.mats[mat_idx].flags & RTMI_MATFLAG_NEEDS_UV) != 0u;
+            hp = lo + ld * closest; // ray.pointing_at(t)
+            if (PM.type == RTMI_PRIM_SPHERE || PM.type == RTMI_PRIM_MSPHERE) {
+                F3 c = f3(A.x, A.y, A.z);
+                if (PM.type == RTMI_PRIM_MSPHERE) c = moving_center(A, sc.prim_b[idx], PM.inv_dt, pa.rtime);
+                hn = vdiv(hp - c, A.w); // sphere.rs:50 — outward, never face-forwarded
+                if (needs_uv) sphere_uv(hn, (ext & RTMI_EXT_UV_BOOK) != 0u, hu, hv);
+            } else {
+                int plane;
+                float x0, y0, x1, y1;
+                if (PM.type == RTMI_PRIM_RECT) {
+                    plane = (int)((PM.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
+                    x0 = A.x; y0 = A.y; x1 = A.z; y1 = A.w;
+                } else { // cube face -> its rect (cube.rs:21-74)
+                    const float4 B = sc.prim_b[idx];
+                    const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
+                    if (face < 2) { plane = 2; x0 = ax; y0 = ay; x1 = bx; y1 = by; }
+                    else if (face < 4) { plane = 1; x0 = az; y0 = ax; x1 = bz; y1 = bx; }
+                    else { plane = 0; x0 = ay; y0 = az; x1 = by; y1 = bz; }
+                }
+                hn = f3(plane == 0 ? 1.0f : 0.0f, plane == 1 ? 1.0f : 0.0f, plane == 2 ? 1.0f : 0.0f); // rect.rs:58-59
+                if (needs_uv) { // rect.rs:52-56
+                    const float x = plane == 0 ? lo.y + closest * ld.y : (plane == 1 ? lo.z + closest * ld.z : lo.x + closest * ld.x);
+                    const float y = plane == 0 ? lo.z + closest * ld.z : (plane == 1 ? lo.x + closest * ld.x : lo.y + closest * ld.y);
+                    hu = (x - x0) / (x1 - x0);
+                    hv = (y - y0) / (y1 - y0);
+                }
+            }
+            if (I.xform_count > 0) xform_hit(sc.xforms, I.xform_first, I.xform_count, hp, hn);
+            if (((PM.flags ^ I.flags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
+        }
+
+        // Material::emitted / Material::scatter (material.rs).  The rejection sampler and the texture
+        // lookup are needed by several materials; they are evaluated ONCE here for all lanes that need
+        // them (a per-material copy would run the same long code serially for each lane subset).  The
+        // draw order per lane is unchanged: Lambertian/Isotropic/fuzzy Metal draw only inside the sampler,
+        // Dielectric draws its single uniform, DiffuseLight draws nothing.
+        M = sc.mats[mat_idx];
+        can_scatter = pa.depth < max_depth; // color.rs:9
+        textured = M.kind == RTMI_MAT_LAMBERTIAN || M.kind == RTMI_MAT_METAL || M.kind == RTMI_MAT_ISOTROPIC;
+        const bool want_sample = can_scatter && (M.kind == RTMI_MAT_LAMBERTIAN || M.kind == RTMI_MAT_ISOTROPIC ||
+                                                 (M.kind == RTMI_MAT_METAL && M.param > 0.0f));
+        if (want_sample) rs = random_in_unit_sphere(g, k0, k1);
+    }
+    const int kind = M.kind;
+    const bool want_tex = active && (kind == RTMI_MAT_DIFFUSE_LIGHT || (can_scatter && textured));
+    const F3 tv = tex_value_wave(sc, want_tex, M.tex, hu, hv, hp, scratch); // every lane of the wavefront
     bool scattered = false;
-    const F3 rd = pa.rd;
-    F3 nd = rd, att = f3(1, 1, 1);
-    // opt-in RTMI_FLAG_FACE_FORWARD (wave-uniform): the opaque materials see the normal turned against the ray
-    if ((ext & RTMI_EXT_FACE_FORWARD) && kind != RTMI_MAT_DIELECTRIC && dot(rd, hn) > 0.0f) hn = -hn;
-    if (can_scatter) {
-        if (kind == RTMI_MAT_LAMBERTIAN) { // material.rs:49-53 (contract: dir = normal + rand)
-            nd = hn + rs;
-            att = tv;
-            scattered = true;
-        } else if (kind == RTMI_MAT_METAL) { // material.rs:75-87
-            F3 refl = reflect(normalize(rd), hn);
-            if (M.param > 0.0f) refl = refl + rs * M.param;
-            if (dot(refl, hn) > 0.0f) {
-                nd = refl;
+    if (active) {
+        if (kind == RTMI_MAT_DIFFUSE_LIGHT) pa.L = pa.L + pa.T * tv; // material.rs:148-150
+        const F3 rd = pa.rd;
+        F3 nd = rd, att = f3(1, 1, 1);
+        // opt-in RTMI_FLAG_FACE_FORWARD (wave-uniform): the opaque materials see the normal turned against the ray
+        if ((ext & RTMI_EXT_FACE_FORWARD) && kind != RTMI_MAT_DIELECTRIC && dot(rd, hn) > 0.0f) hn = -hn;
+        if (can_scatter) {
+            if (kind == RTMI_MAT_LAMBERTIAN) { // material.rs:49-53 (contract: dir = normal + rand)
+                nd = hn + rs;
+                att = tv;
+                scattered = true;
+            } else if (kind == RTMI_MAT_METAL) { // material.rs:75-87
+                F3 refl = reflect(normalize(rd), hn);
+                if (M.param > 0.0f) refl = refl + rs * M.param;
+                if (dot(refl, hn) > 0.0f) {
+                    nd = refl;
+                    att = tv;
+                    scattered = true;
+                }
+            } else if (kind == RTMI_MAT_DIELECTRIC) { // material.rs:106-126
+                F3 outward;
+                float ni_over_nt, cosine;
+                const float ddn = dot(rd, hn);
+                if (ddn > 0.0f) {
+                    cosine = M.param * ddn / norm(rd);
+                    outward = -hn;
+                    ni_over_nt = M.param;
+                } else {
+                    cosine = -ddn / norm(rd);
+                    outward = hn;
+                    ni_over_nt = 1.0f / M.param;
+                }
+                F3 refr;
+                bool took_refraction = false;
+                if (refract(rd, outward, ni_over_nt, refr)) {
+                    const float reflect_prob = schlick(cosine, M.param);
+                    if (rng_uniform(g, k0, k1) >= reflect_prob) { nd = refr; took_refraction = true; }
+                }
+                if (!took_refraction) nd = reflect(rd, hn);
+                scattered = true;
+            } else if (kind == RTMI_MAT_ISOTROPIC) { // material.rs:165-168
+                nd = rs;
                 att = tv;
                 scattered = true;
             }
-        } else if (kind == RTMI_MAT_DIELECTRIC) { // material.rs:106-126
-            F3 outward;
-            float ni_over_nt, cosine;
-            const float ddn = dot(rd, hn);
-            if (ddn > 0.0f) {
-                cosine = M.param * ddn / norm(rd);
-                outward = -hn;
-                ni_over_nt = M.param;
-            } else {
-                cosine = -ddn / norm(rd);
-                outward = hn;
-                ni_over_nt = 1.0f / M.param;
-            }
-            F3 refr;
-            bool took_refraction = false;
-            if (refract(rd, outward, ni_over_nt, refr)) {
-                const float reflect_prob = schlick(cosine, M.param);
-                if (rng_uniform(g, k0, k1) >= reflect_prob) { nd = refr; took_refraction = true; }
-            }
-            if (!took_refraction) nd = reflect(rd, hn);
-            scattered = true;
-        } else if (kind == RTMI_MAT_ISOTROPIC) { // material.rs:165-168
-            nd = rs;
-            att = tv;
-            scattered = true;
         }
-    }
-    if (scattered) {
-        pa.T = pa.T * att;
-        pa.ro = hp;
-        pa.rd = nd;
-        pa.depth++;
+        if (scattered) {
+            pa.T = pa.T * att;
+            pa.ro = hp;
+            pa.rd = nd;
+            pa.depth++;
+        }
     }
     return scattered;
 }

@@ -134,10 +134,20 @@ def test_scene_validation_walks_the_trees(host):
     rc, msg = _create_rc(d)
     assert rc == 1 and "reached twice" in msg
     nodes[inner].left = saved
-    # shared subtree (two parents, no cycle)
+    # right == left is the reference's one-element BVHNode (bvh.rs:44-45): legal, visited once
+    saved_r = nodes[root].right
     nodes[root].right = nodes[root].left
     rc, msg = _create_rc(d)
+    assert rc in ok_codes, msg
+    nodes[root].right = saved_r
+    # shared subtree (two different parents, no cycle)
+    other = nodes[root].right
+    assert other >= 0 and nodes[other].left != inner
+    saved_o = nodes[other].left
+    nodes[other].left = inner
+    rc, msg = _create_rc(d)
     assert rc == 1 and "reached twice" in msg
+    nodes[other].left = saved_o
 
     # understated depths
     keep, d, nodes, alt = _desc_with_private_trees(host)

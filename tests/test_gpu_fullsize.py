@@ -28,7 +28,7 @@ def test_fast_cooperative_equals_exact_at_full_size(host, name, nx, ny, ns):
     assert np.array_equal(fast["rgb8"], exact["rgb8"])
     if name != "cornell_box":
         assert fast["rgb8"].max() == 0  # reference-faithful: no reachable emitter
-        assert int(np.count_nonzero(fast["sig"])) > 0.9 * nx * ny  # ... but the paths themselves are pinned
+        assert int(np.count_nonzero(fast["sig"])) > 0.5 * nx * ny  # ... but the paths themselves are pinned (0 = a camera ray that misses everything)
     else:
         assert 0.05 < float(fast["linear"].mean()) < 1.0
 
@@ -68,5 +68,5 @@ def test_c5_per_rank_workload_of_the_8_gpu_config(host, rank):
     assert out["fast"][2]["samples"] == out["exact"][2]["samples"] > 1.29e9
     assert np.array_equal(out["fast"][1], out["exact"][1])
     assert np.array_equal(out["fast"][0], out["exact"][0])
-    assert int(np.count_nonzero(out["fast"][1])) > 0.9 * sc.local_tiles(p) * 64
+    assert int(np.count_nonzero(out["fast"][1])) > 0.5 * sc.local_tiles(p) * 64
     assert int((out["fast"][0][:, 3] & 0xffffff).max()) == 0  # reference-faithful: black

@@ -153,6 +153,10 @@ def test_textures(api):  # texture.rs
     assert np.allclose(api.tex_value(im, 0.99, 0.0, (0, 0, 0)), data[9:12] / 255.0)     # clamped to nx-1, ny-1
     assert np.allclose(api.tex_value(im, -3.0, 7.0, (0, 0, 0)), data[0:3] / 255.0)      # `as usize` saturates at 0
     assert np.allclose(api.tex_value(im, float("nan"), 1.0, (0, 0, 0)), data[0:3] / 255.0)
+    # `as usize` saturates at the top too: +inf and values beyond 2^32 / 2^64 land on nx-1 / ny-1 (texture.rs:91-101)
+    for big in (float("inf"), 1e10, 1e25):
+        assert np.allclose(api.tex_value(im, big, 1.0, (0, 0, 0)), data[3:6] / 255.0)       # i = nx-1, j = 0
+        assert np.allclose(api.tex_value(im, 0.0, -big, (0, 0, 0)), data[6:9] / 255.0)      # i = 0, j = ny-1
 
 
 def test_perlin_tables_and_noise_range(api):  # perlin.rs

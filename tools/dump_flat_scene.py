@@ -1,0 +1,105 @@
+#!/usr/bin/env python3
+"""Golden dumps of the C++ lowering (raytracing_rust_amd/host/rt_host.cpp) for the Rust shim to diff against.
+
+    python tools/dump_flat_scene.py [--check]      writes / checks tests/golden/flat_<scene>.bin.gz
+
+bindings/rust/src/lower.rs mirrors the C++ SceneBuilder function by function and cannot be compiled in this image
+(no Rust toolchain).  On a machine with cargo, `rtmi::dump::flat_scene_bytes(&lower_world(&scenes::final_scene(1,
+false, earth))?)` must equal the gunzipped bytes of tests/golden/flat_final_scene.bin.gz byte for byte; likewise
+cornell_box.  Format "RTMIFLT1" (little endian):
+    8 B magic | 11 x u32: n_items n_prims n_nodes n_alt_nodes n_xforms n_materials n_textures n_perlin n_images
+    max_bvh_depth alt_max_depth | 2 x f32: bvh_time_lo bvh_time_hi | u64 image_bytes | u64 FNV-1a of image_data
+    then the arrays of include/rtmi.h, raw, in this order: items, prim_a, prim_b, prim_meta, prim_gate, nodes,
+    alt_nodes, xforms, materials, textures, perlin, images   (reserved / pad words written as zero)
+"""
+import ctypes as C
+import gzip
+import os
+import struct
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SCENES = ["cornell_box", "final_scene"]
+
+
+def fnv1a64(data):
+    """FNV-1a, 64 bit, over the bytes (sequential by construction: ~1 s for the 1.5 MB earth texture)."""
+    h = 0xCBF29CE484222325
+    for b in data:
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def flat_scene_bytes(desc):
+    from raytracing_rust_amd import abi
+
+    d = desc
+    out = [b"RTMIFLT1",
+           struct.pack("<11I", d.n_items, d.n_prims, d.n_nodes, d.n_alt_nodes, d.n_xforms, d.n_materials, d.n_textures,
+                       d.n_perlin, d.n_images, d.max_bvh_depth, d.alt_max_depth),
+           struct.pack("<2f", d.bvh_time_lo, d.bvh_time_hi)]
+    img = C.string_at(d.image_data, d.image_bytes) if d.image_bytes else b""
+    out.append(struct.pack("<2Q", d.image_bytes, fnv1a64(img)))
+
+    def raw(ptr, count, elem_size):
+        return C.string_at(ptr, count * elem_size) if count else b""
+
+    out.append(raw(d.items, d.n_items, C.sizeof(abi.Item)))
+    out.append(raw(d.prim_a, d.n_prims, 16))
+    out.append(raw(d.prim_b, d.n_prims, 16))
+    out.append(raw(d.prim_meta, d.n_prims, C.sizeof(abi.PrimMeta)))
+    out.append(raw(d.prim_gate, d.n_prims, 32))
+    nodes = (abi.BvhNode * d.n_nodes)()
+    if d.n_nodes:
+        C.memmove(nodes, d.nodes, C.sizeof(nodes))
+    for n in nodes:
+        n.pad[0] = n.pad[1] = 0
+    out.append(bytes(nodes))
+    alt = (abi.Bvh4Node * d.n_alt_nodes)()
+    if d.n_alt_nodes:
+        C.memmove(alt, d.alt_nodes, C.sizeof(alt))
+    for n in alt:
+        for k in range(4):
+            n.pad[k] = 0
+    out.append(bytes(alt))
+    out.append(raw(d.xforms, d.n_xforms, C.sizeof(abi.Xform)))
+    out.append(raw(d.materials, d.n_materials, C.sizeof(abi.Material)))
+    out.append(raw(d.textures, d.n_textures, C.sizeof(abi.Texture)))
+    out.append(raw(d.perlin, d.n_perlin, C.sizeof(abi.Perlin)))
+    out.append(raw(d.images, d.n_images, C.sizeof(abi.ImageDesc)))
+    return b"".join(out)
+
+
+def dump(name):
+    from raytracing_rust_amd import Host, scenes
+
+    host = Host()
+    _, world = scenes.build(host, name, 64, 64, seed=1)
+    sc = host.lower(world)
+    data = flat_scene_bytes(sc.desc())
+    host.free_all()
+    return data
+
+
+def path_of(name):
+    return os.path.join(ROOT, "tests", "golden", "flat_%s.bin.gz" % name)
+
+
+def main():
+    check = "--check" in sys.argv
+    for name in SCENES:
+        data = dump(name)
+        if check:
+            old = gzip.decompress(open(path_of(name), "rb").read())
+            print(name, "OK" if old == data else "DIFFERS", len(data), "bytes")
+            if old != data:
+                sys.exit(1)
+        else:
+            with open(path_of(name), "wb") as f:
+                f.write(gzip.compress(data, 9, mtime=0))
+            print(name, len(data), "bytes ->", os.path.getsize(path_of(name)), "gz")
+
+
+if __name__ == "__main__":
+    main()
