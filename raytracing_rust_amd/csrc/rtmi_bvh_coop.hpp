@@ -72,27 +72,31 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
     const unsigned long long m_act = __ballot(active);
     have = false;
     if (m_act == 0ull) return; // wave-uniform: nobody enters this tree
-    // ---- publish ray contexts, push roots
+    // ---- publish ray contexts; every owner starts as the worker of its own root entry (no pool round trip, its ray
+    // context is already in registers)
     best[lane] = COOP_SENTINEL;
-    if (active) {
-        // 48 B per ray keeps the wave's LDS under 10 KB; a and inv_a are recomputed by a worker when it
-        // first tests a sphere of this ray (same operations on the same values: bit-identical)
-        ctx[lane * 3 + 0] = make_float4(R.o.x, R.o.y, R.o.z, time);
-        ctx[lane * 3 + 1] = make_float4(R.d.x, R.d.y, R.d.z, q_min);
-        ctx[lane * 3 + 2] = make_float4(R.inv_d.x, R.inv_d.y, R.inv_d.z, q_max);
-        const int pos = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_act, 0u));
-        pool[pos] = make_uint2(((uint32_t)lane << 26) | (uint32_t)root, __float_as_uint(q_min)); // root entry distance: conservative
-    }
-    int top = __popcll(m_act), gtop = 0; // entries in the LDS part / in the spilled (older) part of the stack
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
     uint32_t cur = COOP_NONE; // 26-bit node/leaf encoding of the entry this worker holds
     int ray = 0, cray = -1, aray = -1; // ray of the held entry; ray whose context / whose a, inv_a are loaded
     float tent = 0.0f;
     RayF W;                   // context of ray `cray`
     W.o = f3(0, 0, 0); W.d = f3(0, 0, 1); W.inv_d = f3(0, 0, 0); W.a = 1.0f; W.inv_a = 1.0f;
     float wtime = 0.0f, wqmin = 0.0f, wqmax = 0.0f, wmabs = 0.0f;
+    if (active) {
+        // 48 B per ray keeps the wave's LDS under 10 KB; a and inv_a are recomputed by a worker when it
+        // first tests a sphere of this ray (same operations on the same values: bit-identical)
+        ctx[lane * 3 + 0] = make_float4(R.o.x, R.o.y, R.o.z, time);
+        ctx[lane * 3 + 1] = make_float4(R.d.x, R.d.y, R.d.z, q_min);
+        ctx[lane * 3 + 2] = make_float4(R.inv_d.x, R.inv_d.y, R.inv_d.z, q_max);
+        cur = (uint32_t)root; ray = lane; cray = lane;
+        tent = q_min; // root entry distance: conservative
+        W.o = R.o; W.d = R.d; W.inv_d = R.inv_d;
+        wtime = time; wqmin = q_min; wqmax = q_max;
+        wmabs = scale * (1.0f / 8192.0f) *
+                fminf(fminf(__builtin_fabsf(W.inv_d.x), __builtin_fabsf(W.inv_d.y)), __builtin_fabsf(W.inv_d.z));
+    }
+    int top = 0, gtop = 0; // entries in the LDS part / in the spilled (older) part of the stack
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 
     // The hot loop runs until the LDS part is empty with all workers idle, or too full for 64 more pushes; the
     // rare handling of both (refill from / spill to global memory) sits in the outer loop, outside the hot
@@ -128,6 +132,15 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         uint32_t wkeep = 0u;              // bit c: child c is published
         uint32_t wch[4] = {0u, 0u, 0u, 0u};
         float wtn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef RTMI_EARLY_NODE
+        // The record of a 4-wide node depends on `cur` alone: its fetch starts here, ahead of the LDS reads of the
+        // ray context and of the best hit, so that the two latencies overlap instead of adding up.
+        float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0, e2 = e0, e3 = e0, e4 = e0, e5 = e0, e6 = e0;
+        if (W4 && cur != COOP_NONE && !(cur & (1u << 25))) {
+            const float4 *n = sc.nodes4 + (size_t)cur * 8;
+            e0 = n[0]; e1 = n[1]; e2 = n[2]; e3 = n[3]; e4 = n[4]; e5 = n[5]; e6 = n[6];
+        }
+#endif
         if (cur != COOP_NONE) {
             if (ray != cray) { // switch ray context
                 const float4 c0 = ctx[ray * 3 + 0], c1 = ctx[ray * 3 + 1], c2 = ctx[ray * 3 + 2];
@@ -153,9 +166,13 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
                 // These boxes only cull (acceptance is the primitive's own test and its gate) and are padded beyond
                 // every primitive, so the slab test may take min/max instead of the reference's sign select: a ray
                 // lying exactly in a box plane (NaN from 0 * inf) cannot hit anything inside the padding anyway.
+#ifdef RTMI_EARLY_NODE
+                const float4 mnx = e0, mny = e1, mnz = e2, mxx = e3, mxy = e4, mxz = e5, chf = e6;
+#else
                 const float4 *n = sc.nodes4 + (size_t)cur * 8; // minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] child[4] -
                 const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5];
                 const float4 chf = n[6];
+#endif
                 const float ax0[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ax1[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
                 const float ay0[4] = {mny.x, mny.y, mny.z, mny.w}, ay1[4] = {mxy.x, mxy.y, mxy.z, mxy.w};
                 const float az0[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, az1[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
@@ -212,11 +229,13 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
                     W.inv_a = 1.0f / W.a;
                     aray = ray;
                 }
+                // the gate box is fetched together with the primitive's planes, not after its test: one memory latency
+                // per leaf instead of two on the path of every accepted hit
+                float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+                if (EXT && gated) { g0 = sc.gate[idx * 2]; g1 = sc.gate[idx * 2 + 1]; }
                 bool hit = prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf);
-                if (EXT && hit && gated) { // alternative tree: the reference reaches this leaf iff its parent's box passes
-                    const float4 g0 = sc.gate[idx * 2], g1 = sc.gate[idx * 2 + 1];
-                    hit = aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, W, wqmin, wqmax);
-                }
+                // alternative tree: the reference reaches this leaf iff its parent's box passes
+                if (EXT && hit && gated) hit = aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, W, wqmin, wqmax);
                 if (hit) {
                     const unsigned long long k = ((unsigned long long)f2sort(t) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)pf);
                     atomicMin(&best[ray], k);
@@ -308,12 +327,11 @@ __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_i
     bool any = false;
     if (active) {
         for (int k = 0; k < I.count; k++) {
-            const int idx = I.first + k;
-            const int type = sc.meta[idx].type;
+            const int idx = I.first + k; // wave-uniform
             float t;
             int pf;
             prof_tick<PROF>(prof, 13, true);
-            if (prim_test(sc, type, idx, r, time, q_min, cl, t, pf)) { cl = t; any = true; pf_out = pf; }
+            if (prim_test_uniform(sc, idx, r, time, q_min, cl, t, pf)) { cl = t; any = true; pf_out = pf; }
         }
     }
     t_out = cl;

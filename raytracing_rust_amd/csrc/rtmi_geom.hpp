@@ -4,6 +4,17 @@
 #pragma once
 #include "rtmi_types.hpp"
 
+// Wave-uniform reads (the item record, its transforms, the primitives of a list item: every lane reads the same
+// address) go through the constant address space: the compiler then issues scalar loads (s_load_dwordx4 into
+// SGPRs) instead of 64 identical vector loads — fewer VALU address computations, fewer VGPRs, the vector memory
+// pipe left to the divergent gathers.  Legal because the scene arrays are never written while a render kernel
+// runs.  Measured: final_scene +2.1 %, cornell_box +6 %.
+#if !defined(RTMI_NO_SLOAD) && defined(__HIP_DEVICE_COMPILE__)
+#define RTMI_UNIFORM_LOAD(T, ptr) (*reinterpret_cast<const T __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(ptr)))
+#else
+#define RTMI_UNIFORM_LOAD(T, ptr) (*(ptr))
+#endif
+
 // ----------------------------------------------------------------------------------
 // instance transforms — src/traslate.rs:18-24, src/rotate.rs:85-113
 // ----------------------------------------------------------------------------------
@@ -17,11 +28,13 @@ __device__ __forceinline__ void rot_inv(float s, float c, float &a, float &b) {
     float nb = s * a + c * b;
     a = na; b = nb;
 }
-// world -> object; returns true when the direction changed (a rotation was applied)
+// world -> object; returns true when the direction changed (a rotation was applied).  UNIFORM: `first` and `count`
+// are the same in every lane (the item loop), so the records come through scalar loads.
+template <bool UNIFORM = false>
 __device__ __forceinline__ bool xform_ray(const rtmi_xform *xf, int first, int count, F3 &o, F3 &d) {
     bool rotated = false;
     for (int k = 0; k < count; k++) {
-        const rtmi_xform X = xf[first + k];
+        const rtmi_xform X = UNIFORM ? RTMI_UNIFORM_LOAD(rtmi_xform, xf + first + k) : xf[first + k];
         switch (X.kind) {
         case RTMI_XF_TRANSLATE: o = o - f3(X.x, X.y, X.z); break;
         case RTMI_XF_ROTATE_X: rot_fwd(X.x, X.y, o.y, o.z); rot_fwd(X.x, X.y, d.y, d.z); rotated = true; break;
@@ -166,6 +179,28 @@ __device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx,
     const float4 A = sc.prim_a[idx];
     const float4 B = sc.prim_b[idx];
     const rtmi_prim_meta M = sc.meta[idx];
+    bool h = false;
+    int face = 0;
+    if (type == RTMI_PRIM_SPHERE) {
+        h = sphere_test(r, f3(A.x, A.y, A.z), A.w, t_min, t_max, t_out);
+    } else if (type == RTMI_PRIM_MSPHERE) {
+        h = sphere_test(r, moving_center(A, B, M.inv_dt, time), A.w, t_min, t_max, t_out);
+    } else if (type == RTMI_PRIM_RECT) {
+        const int plane = (int)((M.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
+        h = rect_test_rt(plane, A, B.x, r, t_min, t_max, t_out);
+    } else {
+        h = cube_test(A, B, r, t_min, t_max, t_out, face);
+    }
+    pf = (idx << 3) | face;
+    return h;
+}
+// the same for a wave-uniform primitive index (list items)
+__device__ __forceinline__ bool prim_test_uniform(const DevScene &sc, int idx, const RayF &r, float time,
+                                                  float t_min, float t_max, float &t_out, int &pf) {
+    const float4 A = RTMI_UNIFORM_LOAD(float4, sc.prim_a + idx);
+    const float4 B = RTMI_UNIFORM_LOAD(float4, sc.prim_b + idx);
+    const rtmi_prim_meta M = RTMI_UNIFORM_LOAD(rtmi_prim_meta, sc.meta + idx);
+    const int type = M.type;
     bool h = false;
     int face = 0;
     if (type == RTMI_PRIM_SPHERE) {

@@ -198,10 +198,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
             for (uint32_t it = 0; it < sc.n_items; it++) { // executed by all 64 lanes
-                const rtmi_item I = sc.items[it];
+                const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, sc.items + it);
                 RayF R = W;
                 if (I.xform_count > 0) {
-                    if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
+                    if (xform_ray<true>(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
                 }
                 const int slot = 1 + (it < 11u ? (int)it : 11);
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
@@ -216,11 +216,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     float t1 = 0.0f, t2 = 0.0f, tm;
                     int pf;
                     bool h1, h2;
-                    if (I.kind == RTMI_ITEM_LIST && I.count == 1 && sc.meta[I.first].type == RTMI_PRIM_SPHERE) {
+                    if (I.kind == RTMI_ITEM_LIST && I.count == 1 && RTMI_UNIFORM_LOAD(rtmi_prim_meta, sc.meta + I.first).type == RTMI_PRIM_SPHERE) {
                         // boundary = one static sphere (wave-uniform test): both boundary queries are roots of the
                         // same quadratic, evaluated once (same expressions as two Sphere::hit calls: same bits)
                         h1 = false; h2 = false;
-                        if (need) sphere_two_queries(R, sc.prim_a[I.first], h1, t1, h2, t2);
+                        if (need) sphere_two_queries(R, RTMI_UNIFORM_LOAD(float4, sc.prim_a + I.first), h1, t1, h2, t2);
                     } else {
                         h1 = geom_query_coop<PROF, EXT, false>(sc, I, P.use_alt != 0u, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
                         h2 = geom_query_coop<PROF, EXT, false>(sc, I, P.use_alt != 0u, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);

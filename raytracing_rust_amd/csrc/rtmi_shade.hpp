@@ -84,7 +84,9 @@ __device__ __forceinline__ float perlin_corner_term(const rtmi_perlin *pn, F3 tp
 // ascending, starting from 0.0), and the octaves are combined in order with the weights 1, 1/2, ... — the same
 // operations on the same values as perlin_turb, so the same bits; 2 dependent table look-ups instead of 14.
 // `scratch`: 64 floats of LDS private to the wavefront.
-__device__ __forceinline__ float perlin_turb7_wave(const rtmi_perlin *pn, F3 p, float *scratch) {
+// out of line: inlined, its registers cost every scene 1.5-2 % (spills in the shading code) whether it has a
+// NoiseTexture or not; the call is taken only when some lane of the batch wants turbulence
+__device__ __attribute__((noinline)) float perlin_turb7_wave(const rtmi_perlin *pn, F3 p, float *scratch) {
     const int lane = threadIdx.x & 63;
     const int o = lane >> 3, c = lane & 7;
     float term = 0.0f;
