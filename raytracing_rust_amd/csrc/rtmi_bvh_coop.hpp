@@ -132,15 +132,6 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         uint32_t wkeep = 0u;              // bit c: child c is published
         uint32_t wch[4] = {0u, 0u, 0u, 0u};
         float wtn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#ifdef RTMI_EARLY_NODE
-        // The record of a 4-wide node depends on `cur` alone: its fetch starts here, ahead of the LDS reads of the
-        // ray context and of the best hit, so that the two latencies overlap instead of adding up.
-        float4 e0 = make_float4(0.f, 0.f, 0.f, 0.f), e1 = e0, e2 = e0, e3 = e0, e4 = e0, e5 = e0, e6 = e0;
-        if (W4 && cur != COOP_NONE && !(cur & (1u << 25))) {
-            const float4 *n = sc.nodes4 + (size_t)cur * 8;
-            e0 = n[0]; e1 = n[1]; e2 = n[2]; e3 = n[3]; e4 = n[4]; e5 = n[5]; e6 = n[6];
-        }
-#endif
         if (cur != COOP_NONE) {
             if (ray != cray) { // switch ray context
                 const float4 c0 = ctx[ray * 3 + 0], c1 = ctx[ray * 3 + 1], c2 = ctx[ray * 3 + 2];
@@ -166,13 +157,9 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
                 // These boxes only cull (acceptance is the primitive's own test and its gate) and are padded beyond
                 // every primitive, so the slab test may take min/max instead of the reference's sign select: a ray
                 // lying exactly in a box plane (NaN from 0 * inf) cannot hit anything inside the padding anyway.
-#ifdef RTMI_EARLY_NODE
-                const float4 mnx = e0, mny = e1, mnz = e2, mxx = e3, mxy = e4, mxz = e5, chf = e6;
-#else
                 const float4 *n = sc.nodes4 + (size_t)cur * 8; // minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] child[4] -
                 const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5];
                 const float4 chf = n[6];
-#endif
                 const float ax0[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ax1[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
                 const float ay0[4] = {mny.x, mny.y, mny.z, mny.w}, ay1[4] = {mxy.x, mxy.y, mxy.z, mxy.w};
                 const float az0[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, az1[4] = {mxz.x, mxz.y, mxz.z, mxz.w};

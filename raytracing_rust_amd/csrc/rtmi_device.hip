@@ -239,7 +239,22 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     s->device = device;
     s->meta = *d;
     const float4 *nodes4 = nullptr;
-    rc = upload(s, d->items, d->n_items, &s->dev.items);
+    {
+        // device copy of the items: a ConstantMedium whose boundary is one static sphere (the common case:
+        // tests/test.rs:471-483) carries that sphere in its unused root-box words, marked by a device-only flag bit,
+        // so the kernel's fused two-root boundary query needs no dependent loads of the primitive's meta and planes
+        std::vector<rtmi_item> items(d->items, d->items + d->n_items);
+        for (rtmi_item &it : items) {
+            it.flags &= (RTMI_ITEMFLAG_FLIP | RTMI_ITEMFLAG_MEDIUM);
+            if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && it.kind == RTMI_ITEM_LIST && it.count == 1 &&
+                d->prim_meta[it.first].type == RTMI_PRIM_SPHERE) {
+                it.flags |= RTMI_ITEMFLAG_DEV_MEDIUM_SPHERE;
+                memcpy(it.root_min, d->prim_a + (size_t)it.first * 4, 3 * sizeof(float));
+                it.root_max[0] = d->prim_a[(size_t)it.first * 4 + 3];
+            }
+        }
+        rc = upload(s, items.data(), d->n_items, &s->dev.items);
+    }
     if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_a), d->n_prims, &s->dev.prim_a);
     if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_b), d->n_prims, &s->dev.prim_b);
     if (!rc) rc = upload(s, d->prim_meta, d->n_prims, &s->dev.meta);
@@ -264,6 +279,21 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
                 }
             if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(alt.data()), (size_t)d->n_alt_nodes * 8, &s->dev.nodes4);
         }
+    }
+    if (!rc) { // shading records: see DevScene
+        const auto fill = [&](float *r, int32_t material) {
+            const rtmi_material &m = d->materials[material];
+            memcpy(r + 4, &m, 16);
+            if (m.kind != RTMI_MAT_DIELECTRIC) memcpy(r + 8, &d->textures[m.tex], 32);
+        };
+        std::vector<float> sp((size_t)d->n_prims * 16, 0.0f), sm((size_t)d->n_materials * 16, 0.0f);
+        for (uint32_t i = 0; i < d->n_prims; i++) {
+            memcpy(&sp[(size_t)i * 16], d->prim_a + (size_t)i * 4, 16);
+            fill(&sp[(size_t)i * 16], d->prim_meta[i].material);
+        }
+        for (uint32_t i = 0; i < d->n_materials; i++) fill(&sm[(size_t)i * 16], (int32_t)i);
+        rc = upload(s, reinterpret_cast<const float4 *>(sp.data()), (size_t)d->n_prims * 4, &s->dev.shade_prim);
+        if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(sm.data()), (size_t)d->n_materials * 4, &s->dev.shade_mat);
     }
     if (!rc) rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms);
     if (!rc) rc = upload(s, d->materials, d->n_materials, &s->dev.mats);

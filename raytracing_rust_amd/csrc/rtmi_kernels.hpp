@@ -216,11 +216,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     float t1 = 0.0f, t2 = 0.0f, tm;
                     int pf;
                     bool h1, h2;
-                    if (I.kind == RTMI_ITEM_LIST && I.count == 1 && RTMI_UNIFORM_LOAD(rtmi_prim_meta, sc.meta + I.first).type == RTMI_PRIM_SPHERE) {
-                        // boundary = one static sphere (wave-uniform test): both boundary queries are roots of the
-                        // same quadratic, evaluated once (same expressions as two Sphere::hit calls: same bits)
+                    if (I.flags & RTMI_ITEMFLAG_DEV_MEDIUM_SPHERE) {
+                        // boundary = one static sphere (wave-uniform test; the sphere travels in the item record): both
+                        // boundary queries are roots of the same quadratic, evaluated once (same expressions as two
+                        // Sphere::hit calls: same bits)
                         h1 = false; h2 = false;
-                        if (need) sphere_two_queries(R, RTMI_UNIFORM_LOAD(float4, sc.prim_a + I.first), h1, t1, h2, t2);
+                        if (need) sphere_two_queries(R, make_float4(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0]), h1, t1, h2, t2);
                     } else {
                         h1 = geom_query_coop<PROF, EXT, false>(sc, I, P.use_alt != 0u, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
                         h2 = geom_query_coop<PROF, EXT, false>(sc, I, P.use_alt != 0u, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);

@@ -119,13 +119,12 @@ __device__ __attribute__((noinline)) float perlin_turb7_wave(const rtmi_perlin *
 // corners, two dependent table look-ups each: ~1700 instructions and 14 memory latencies per lane) is what a few
 // lanes of a shading batch need while the others wait, so those few points are evaluated one after the other by
 // all 64 lanes together (perlin_turb7_wave); measured on final_scene: Perlin cost 4.3 % of the frame.
-__device__ __forceinline__ F3 tex_value_wave(const DevScene &sc, bool want, int tex, float u, float v, F3 p, float *scratch) {
+__device__ __forceinline__ F3 tex_value_wave(const DevScene &sc, bool want, rtmi_texture t, float u, float v, F3 p, float *scratch) {
     F3 out = f3(1, 1, 1);
     bool noise = false;
     int table = 0;
     float nscale = 0.0f;
-    if (want) {
-        rtmi_texture t = sc.texs[tex];
+    if (want) { // t = the material's texture record (it came with the shading record)
         for (int guard = 0; guard < 16 && t.kind == RTMI_TEX_CHECKER; guard++) {
             const float s = rtmi_sinf(10.0f * p.x) * rtmi_sinf(10.0f * p.y) * rtmi_sinf(10.0f * p.z);
             t = sc.texs[s < 0.0f ? t.i0 : t.i1];
@@ -287,21 +286,29 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
     M.kind = -1; M.tex = 0; M.param = 0.0f; M.flags = 0u;
     bool can_scatter = false, textured = false;
     F3 rs = f3(0, 0, 0);
+    rtmi_texture T0;
+    T0.kind = RTMI_TEX_SOLID; T0.i0 = 0; T0.i1 = 0; T0.pad = 0; T0.f0 = 1.0f; T0.f1 = 1.0f; T0.f2 = 1.0f; T0.f3 = 0.0f;
     if (active) {
-        const rtmi_item I = sc.items[best_item];
-        int mat_idx;
+        // of the item only {flags, xform_first, xform_count, medium_material} are needed: one 16-B fetch
+        struct __attribute__((aligned(4))) ItemWords { int x, y, z, w; }; // 4-byte aligned: offset 12 of a 64-B record
+        const ItemWords IW = *reinterpret_cast<const ItemWords *>(reinterpret_cast<const char *>(sc.items + best_item) + 12);
+        const uint32_t iflags = (uint32_t)IW.x;
+        const int xform_first = IW.y, xform_count = IW.z;
+        float4 rec_mat, rec_t0, rec_t1; // material record + its texture record, fetched with the hit's geometry
         if (best_medium) {
+            const float4 *rec = sc.shade_mat + (size_t)IW.w * 4; // medium_material
+            rec_mat = rec[1]; rec_t0 = rec[2]; rec_t1 = rec[3];
             hp = pa.ro + pa.rd * closest;      // ray.pointing_at(t) — medium.rs:47
             hn = f3(1.0f, 0.0f, 0.0f);         // medium.rs:48
-            mat_idx = I.medium_material;
         } else {
-            F3 lo = pa.ro, ld = pa.rd;
-            if (I.xform_count > 0) xform_ray(sc.xforms, I.xform_first, I.xform_count, lo, ld);
             const int idx = best_pf >> 3, face = best_pf & 7;
+            const float4 *rec = sc.shade_prim + (size_t)idx * 4;
+            const float4 A = rec[0];
+            rec_mat = rec[1]; rec_t0 = rec[2]; rec_t1 = rec[3];
             const rtmi_prim_meta PM = sc.meta[idx];
-            const float4 A = sc.prim_a[idx];
-            mat_idx = PM.material;
-            const bool needs_uv = (sc.mats[mat_idx].flags & RTMI_MATFLAG_NEEDS_UV) != 0u;
+            F3 lo = pa.ro, ld = pa.rd;
+            if (xform_count > 0) xform_ray(sc.xforms, xform_first, xform_count, lo, ld);
+            const bool needs_uv = (__float_as_uint(rec_mat.w) & RTMI_MATFLAG_NEEDS_UV) != 0u;
             hp = lo + ld * closest; // ray.pointing_at(t)
             if (PM.type == RTMI_PRIM_SPHERE || PM.type == RTMI_PRIM_MSPHERE) {
                 F3 c = f3(A.x, A.y, A.z);
@@ -329,8 +336,8 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
                     hv = (y - y0) / (y1 - y0);
                 }
             }
-            if (I.xform_count > 0) xform_hit(sc.xforms, I.xform_first, I.xform_count, hp, hn);
-            if (((PM.flags ^ I.flags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
+            if (xform_count > 0) xform_hit(sc.xforms, xform_first, xform_count, hp, hn);
+            if (((PM.flags ^ iflags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
         }
 
         // Material::emitted / Material::scatter (material.rs).  The rejection sampler and the texture
@@ -338,7 +345,11 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
         // them (a per-material copy would run the same long code serially for each lane subset).  The
         // draw order per lane is unchanged: Lambertian/Isotropic/fuzzy Metal draw only inside the sampler,
         // Dielectric draws its single uniform, DiffuseLight draws nothing.
-        M = sc.mats[mat_idx];
+        M.kind = (int32_t)__float_as_uint(rec_mat.x); M.tex = (int32_t)__float_as_uint(rec_mat.y);
+        M.param = rec_mat.z; M.flags = __float_as_uint(rec_mat.w);
+        T0.kind = (int32_t)__float_as_uint(rec_t0.x); T0.i0 = (int32_t)__float_as_uint(rec_t0.y);
+        T0.i1 = (int32_t)__float_as_uint(rec_t0.z); T0.pad = 0;
+        T0.f0 = rec_t1.x; T0.f1 = rec_t1.y; T0.f2 = rec_t1.z; T0.f3 = rec_t1.w;
         can_scatter = pa.depth < max_depth; // color.rs:9
         textured = M.kind == RTMI_MAT_LAMBERTIAN || M.kind == RTMI_MAT_METAL || M.kind == RTMI_MAT_ISOTROPIC;
         const bool want_sample = can_scatter && (M.kind == RTMI_MAT_LAMBERTIAN || M.kind == RTMI_MAT_ISOTROPIC ||
@@ -347,7 +358,7 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
     }
     const int kind = M.kind;
     const bool want_tex = active && (kind == RTMI_MAT_DIFFUSE_LIGHT || (can_scatter && textured));
-    const F3 tv = tex_value_wave(sc, want_tex, M.tex, hu, hv, hp, scratch); // every lane of the wavefront
+    const F3 tv = tex_value_wave(sc, want_tex, T0, hu, hv, hp, scratch); // every lane of the wavefront
     bool scattered = false;
     if (active) {
         if (kind == RTMI_MAT_DIFFUSE_LIGHT) pa.L = pa.L + pa.T * tv; // material.rs:148-150

@@ -41,6 +41,11 @@ struct DevScene {
     const float4 *gate;  // 2 x float4 per primitive: box of its parent BVHNode in the reference tree (or NULL)
     const float4 *nodes; // 4 x float4 per rtmi_bvh_node
     const float4 *nodes4; // 8 x float4 per rtmi_bvh4_node (alternative trees)
+    // shading records (device-side layout, built by rtmi_scene_create): 4 x float4 = {plane A, material record,
+    // its first-level texture record (32 B)} per primitive / per material — the closest hit's normal, material and
+    // texture arrive with ONE dependent fetch instead of the chain prim -> material -> texture
+    const float4 *shade_prim;
+    const float4 *shade_mat;
     const rtmi_xform *xforms;
     const rtmi_material *mats;
     const rtmi_texture *texs;
@@ -76,6 +81,9 @@ struct DevParams {
     uint32_t use_alt; // cooperative kernel: walk the items' alternative trees, leaves accepted through their gate
     uint32_t ext;     // opt-in extensions / test knobs: RTMI_EXT_*
 };
+// device-only item flag (set by rtmi_scene_create, never part of the ABI): MEDIUM item whose boundary is one static
+// sphere; root_min = its centre, root_max[0] = its radius
+#define RTMI_ITEMFLAG_DEV_MEDIUM_SPHERE (1u << 16)
 #define RTMI_EXT_FACE_FORWARD 1u  // RTMI_FLAG_FACE_FORWARD
 #define RTMI_EXT_UV_BOOK 2u       // RTMI_FLAG_UV_BOOK
 #define RTMI_EXT_TEST_OVERFLOW 4u // RTMI_FLAG_TEST_OVERFLOW
