@@ -217,7 +217,7 @@ typedef struct {
     uint64_t seed;
     uint32_t tile_rank, tile_world; /* this call renders tiles t with t % tile_world == tile_rank */
     uint32_t spp_chunks;            /* sample chunks per tile (one wavefront each); 0 = choose automatically */
-    uint32_t shade_threshold;       /* two-phase kernel: lanes holding a hit before shading starts (0 = default 32) */
+    uint32_t shade_threshold;       /* two-phase kernel: lanes holding a hit before shading starts (0 = default 40) */
     uint64_t path_sig;              /* RTMI_FLAG_PATH_SIG: DEVICE address of rtmi_local_tiles()*64 uint64 (else 0) */
     uint64_t prof;                  /* RTMI_FLAG_PROFILE: DEVICE address of 64 uint64 counters (else 0) */
     uint64_t sample_buffer_bytes;   /* budget of the per-sample radiance buffer (16 B per pixel sample of this rank);

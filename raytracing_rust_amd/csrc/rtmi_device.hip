@@ -477,7 +477,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     const bool fast = (p->flags & RTMI_FLAG_FAST_CULL) != 0u && boxes_valid, sigf = (p->flags & RTMI_FLAG_PATH_SIG) != 0u;
     const dim3 block(64 * WAVES_PER_BLOCK);
     P.stack_depth = s->meta.max_bvh_depth + 1u;
-    P.shade_threshold = p->shade_threshold ? (p->shade_threshold > 64u ? 64u : p->shade_threshold) : 32u; // tuned on C2..C5
+    P.shade_threshold = p->shade_threshold ? (p->shade_threshold > 64u ? 64u : p->shade_threshold) : 40u; // tuned on C2..C5 (r02 sweep: 16..48)
     const size_t dyn_lds = (size_t)WAVES_PER_BLOCK * 2u * P.stack_depth * 64u * sizeof(uint32_t);
     const bool prof = (p->flags & RTMI_FLAG_PROFILE) != 0u, sync = (p->flags & RTMI_FLAG_SYNC) != 0u;
     if (prof) {
