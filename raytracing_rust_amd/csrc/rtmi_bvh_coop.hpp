@@ -98,6 +98,10 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    // children of the 4-wide node visited this round and their entry distances; only read under a bit of `wkeep`, so
+    // they live outside the loop and are not re-initialised every round (16 moves per round otherwise)
+    uint32_t wch[4] = {0u, 0u, 0u, 0u};
+    float wtn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     // The hot loop runs until the LDS part is empty with all workers idle, or too full for 64 more pushes; the
     // rare handling of both (refill from / spill to global memory) sits in the outer loop, outside the hot
     // loop's register allocation.
@@ -129,9 +133,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         uint32_t push_ref = 0u;
         float push_t = 0.0f;
         int npush = 0;                    // W4: up to three of the four children are published
-        uint32_t wkeep = 0u;              // bit c: child c is published
-        uint32_t wch[4] = {0u, 0u, 0u, 0u};
-        float wtn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        uint32_t wkeep = 0u;              // bit c: child c is published (wch / wtn: declared outside the loop)
         if (cur != COOP_NONE) {
             if (ray != cray) { // switch ray context
                 const float4 c0 = ctx[ray * 3 + 0], c1 = ctx[ray * 3 + 1], c2 = ctx[ray * 3 + 2];
@@ -174,6 +176,8 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
                     const float tn = fmaxf(fmaxf(fmaxf(wqmin, fminf(x0, x1)), fminf(y0, y1)), fminf(z0, z1));
                     const float tf = fminf(fminf(fminf(wqmax, fmaxf(x0, x1)), fmaxf(y0, y1)), fmaxf(z0, z1));
                     wtn[c] = tn;
+                    // (the explicit test of the child word stays: a ray with NaN components passes every min/max slab
+                    // test, and an empty slot's reference must never reach the pool)
                     const bool okc = tf > tn && !(tn > limit) && wch[c] != COOP_NONE;
                     if (okc) wkeep |= 1u << c;
                     if (okc && tn < tnear) { nearest = c; tnear = tn; }
@@ -218,11 +222,16 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
                 }
                 // the gate box is fetched together with the primitive's planes, not after its test: one memory latency
                 // per leaf instead of two on the path of every accepted hit
-                float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-                if (EXT && gated) { g0 = sc.gate[idx * 2]; g1 = sc.gate[idx * 2 + 1]; }
-                bool hit = prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf);
-                // alternative tree: the reference reaches this leaf iff its parent's box passes
-                if (EXT && hit && gated) hit = aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, W, wqmin, wqmax);
+                bool hit;
+                if (EXT && gated) { // one 80-B record: planes, meta and the gate box arrive together
+                    const float4 *rec = sc.leaf_rec + (size_t)idx * 5;
+                    const float4 A = rec[0], B = rec[1], M = rec[2], g0 = rec[3], g1 = rec[4];
+                    hit = prim_test_vals(type, idx, A, B, M.z, __float_as_uint(M.y), W, wtime, wqmin, wqmax, t, pf);
+                    // alternative tree: the reference reaches this leaf iff its parent's box passes
+                    if (hit) hit = aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, W, wqmin, wqmax);
+                } else {
+                    hit = prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf);
+                }
                 if (hit) {
                     const unsigned long long k = ((unsigned long long)f2sort(t) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)pf);
                     atomicMin(&best[ray], k);

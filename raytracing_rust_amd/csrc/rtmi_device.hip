@@ -274,11 +274,27 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
             std::vector<rtmi_bvh4_node> alt(d->alt_nodes, d->alt_nodes + d->n_alt_nodes);
             for (rtmi_bvh4_node &n : alt)
                 for (int c = 0; c < 4; c++) {
-                    if (n.child[c] == RTMI_NO_CHILD) n.child[c] = (int32_t)0xffffffffu;
+                    if (n.child[c] == RTMI_NO_CHILD) { // empty slot: a box no ray can enter, whatever the host wrote
+                        n.child[c] = (int32_t)0xffffffffu;
+                        const float big = 3.40282346638528859811704183484516925e+38f;
+                        n.minx[c] = n.miny[c] = n.minz[c] = big;
+                        n.maxx[c] = n.maxy[c] = n.maxz[c] = -big;
+                    }
                     else n.child[c] = enc(n.child[c]); // range-checked by validate()
                 }
             if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(alt.data()), (size_t)d->n_alt_nodes * 8, &s->dev.nodes4);
         }
+    }
+    if (!rc && d->prim_gate) { // leaf records of the gated trees: see DevScene
+        std::vector<float> lr((size_t)d->n_prims * 20, 0.0f);
+        for (uint32_t i = 0; i < d->n_prims; i++) {
+            float *r = &lr[(size_t)i * 20];
+            memcpy(r, d->prim_a + (size_t)i * 4, 16);
+            memcpy(r + 4, d->prim_b + (size_t)i * 4, 16);
+            memcpy(r + 8, &d->prim_meta[i], 16);
+            memcpy(r + 12, d->prim_gate + (size_t)i * 8, 32);
+        }
+        rc = upload(s, reinterpret_cast<const float4 *>(lr.data()), (size_t)d->n_prims * 5, &s->dev.leaf_rec);
     }
     if (!rc) { // shading records: see DevScene
         const auto fill = [&](float *r, int32_t material) {
@@ -317,7 +333,7 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
-        s->slots = cus * 16; // 4 SIMDs x 4 wavefronts (the __launch_bounds__ of the default kernel)
+        s->slots = cus * 4 * 5; // 4 SIMDs x up to 5 wavefronts: capacity of the spill buffer; a launch uses cus * 4 * its waves per SIMD
     }
     for (int i = 0; i < 3; i++)
         if (hipEventCreate(&s->ev[i]) != hipSuccess) {
@@ -515,6 +531,10 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     const bool ext = P.use_alt || deepest > 10u || (p->flags & (1u << 11));
     P.coop_cap = ext ? 512u : P.spill_cap;
     if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
+    // persistent grid: as many wavefronts as the kernel instantiation keeps resident (4 SIMDs x its waves per SIMD)
+    const uint32_t wps_req = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
+    const uint32_t wps_run = (coop && !prof && !sigf && (wps_req == 3u || wps_req == 5u)) ? wps_req : (coop && prof ? 3u : 4u);
+    const uint64_t run_slots = (uint64_t)(s->slots / 20) * 4u * wps_run;
     if (coop) {
         const size_t spill_bytes = (size_t)s->slots * P.spill_cap * sizeof(uint2);
         if (spill_bytes > s->spill_bytes) {
@@ -535,7 +555,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     if (nitems > 0x7fffffffull) return fail(RTMI_ERR_UNSUPPORTED, "too many (tile, chunk) items in one pass");
     // two-phase kernels: persistent wavefronts that take units from the queue; async kernel: one block per unit
     const uint64_t nblocks = async ? (nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK
-                                   : (nitems < (uint64_t)s->slots ? nitems : (uint64_t)s->slots);
+                                   : (nitems < run_slots ? nitems : run_slots);
     const dim3 grid((uint32_t)nblocks);
     blocks_total += grid.x; chunks_total += P.nchunks;
     s->units_total += nitems;
@@ -548,7 +568,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
         hipLaunchKernelGGL((rtmi_render_coop<S, PR, W, E>), grid, block, coop_lds, stream, s->dev, C, P);                \
     } while (0)
     if (coop) {
-        const uint32_t wps = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
+        const uint32_t wps = wps_req;
         if (prof) RTMI_LAUNCH_COOP(false, true, 3, true);
         else if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true);
         else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3, true);

@@ -194,6 +194,24 @@ __device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx,
     pf = (idx << 3) | face;
     return h;
 }
+// a primitive whose planes and meta words are at hand (leaf record of a gated tree)
+__device__ __forceinline__ bool prim_test_vals(int type, int idx, float4 A, float4 B, float m_inv_dt, uint32_t m_flags, const RayF &r,
+                                               float time, float t_min, float t_max, float &t_out, int &pf) {
+    bool h = false;
+    int face = 0;
+    if (type == RTMI_PRIM_SPHERE) {
+        h = sphere_test(r, f3(A.x, A.y, A.z), A.w, t_min, t_max, t_out);
+    } else if (type == RTMI_PRIM_MSPHERE) {
+        h = sphere_test(r, moving_center(A, B, m_inv_dt, time), A.w, t_min, t_max, t_out);
+    } else if (type == RTMI_PRIM_RECT) {
+        const int plane = (int)((m_flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
+        h = rect_test_rt(plane, A, B.x, r, t_min, t_max, t_out);
+    } else {
+        h = cube_test(A, B, r, t_min, t_max, t_out, face);
+    }
+    pf = (idx << 3) | face;
+    return h;
+}
 // the same for a wave-uniform primitive index (list items)
 __device__ __forceinline__ bool prim_test_uniform(const DevScene &sc, int idx, const RayF &r, float time,
                                                   float t_min, float t_max, float &t_out, int &pf) {

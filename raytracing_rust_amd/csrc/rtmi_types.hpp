@@ -38,7 +38,8 @@ struct DevScene {
     const float4 *prim_a;
     const float4 *prim_b;
     const rtmi_prim_meta *meta;
-    const float4 *gate;  // 2 x float4 per primitive: box of its parent BVHNode in the reference tree (or NULL)
+    const float4 *gate;  // 2 x float4 per primitive: box of its parent BVHNode in the reference tree (or NULL); the
+                         // kernels read it through leaf_rec
     const float4 *nodes; // 4 x float4 per rtmi_bvh_node
     const float4 *nodes4; // 8 x float4 per rtmi_bvh4_node (alternative trees)
     // shading records (device-side layout, built by rtmi_scene_create): 4 x float4 = {plane A, material record,
@@ -46,6 +47,9 @@ struct DevScene {
     // texture arrive with ONE dependent fetch instead of the chain prim -> material -> texture
     const float4 *shade_prim;
     const float4 *shade_mat;
+    // leaf records of the gated alternative trees (device-side layout): 5 x float4 = {plane A, plane B, meta, gate min,
+    // gate max} per primitive, so a leaf visit computes one address and touches one or two cache lines instead of five
+    const float4 *leaf_rec;
     const rtmi_xform *xforms;
     const rtmi_material *mats;
     const rtmi_texture *texs;
