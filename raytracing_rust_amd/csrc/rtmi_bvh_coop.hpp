@@ -102,6 +102,52 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
     // they live outside the loop and are not re-initialised every round (16 moves per round otherwise)
     uint32_t wch[4] = {0u, 0u, 0u, 0u};
     float wtn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // One visit of a node of the 4-wide tree held in `cur` (ray context W): tests the four child boxes, keeps the
+    // nearest surviving child in `cur` / `tent`, marks the others in `wkeep` for publication.
+    // These boxes only cull (acceptance is the primitive's own test and its gate) and are padded beyond every
+    // primitive, so the slab test may take min/max instead of the reference's sign select: a ray lying exactly in
+    // a box plane (NaN from 0 * inf) cannot hit anything inside the padding anyway.
+    const auto visit4 = [&](float limit, uint32_t &wkeep, int &npush) {
+        const float4 *n = sc.nodes4 + (size_t)cur * 8; // minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] child[4] -
+        const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5];
+        const float4 chf = n[6];
+        const float ax0[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ax1[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
+        const float ay0[4] = {mny.x, mny.y, mny.z, mny.w}, ay1[4] = {mxy.x, mxy.y, mxy.z, mxy.w};
+        const float az0[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, az1[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+        wch[0] = __float_as_uint(chf.x); wch[1] = __float_as_uint(chf.y); wch[2] = __float_as_uint(chf.z); wch[3] = __float_as_uint(chf.w);
+        int nearest = -1;
+        float tnear = RTMI_FLT_MAX;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const float x0 = (ax0[c] - W.o.x) * W.inv_d.x, x1 = (ax1[c] - W.o.x) * W.inv_d.x;
+            const float y0 = (ay0[c] - W.o.y) * W.inv_d.y, y1 = (ay1[c] - W.o.y) * W.inv_d.y;
+            const float z0 = (az0[c] - W.o.z) * W.inv_d.z, z1 = (az1[c] - W.o.z) * W.inv_d.z;
+            const float tn = fmaxf(fmaxf(fmaxf(wqmin, fminf(x0, x1)), fminf(y0, y1)), fminf(z0, z1));
+            const float tf = fminf(fminf(fminf(wqmax, fmaxf(x0, x1)), fmaxf(y0, y1)), fmaxf(z0, z1));
+            wtn[c] = tn;
+            // (the explicit test of the child word stays: a ray with NaN components passes every min/max slab
+            // test, and an empty slot's reference must never reach the pool)
+            const bool okc = tf > tn && !(tn > limit) && wch[c] != COOP_NONE;
+            if (okc) wkeep |= 1u << c;
+            if (okc && tn < tnear) { nearest = c; tnear = tn; }
+        }
+        if (nearest >= 0) { cur = wch[nearest]; tent = tnear; wkeep &= ~(1u << nearest); } else cur = COOP_NONE;
+        npush = __popc(wkeep); // what is left gets published
+    };
+    // Publication of the marked children of every worker's visit (all 64 lanes call): exclusive prefix sum of the
+    // per-worker counts (0..3) from two ballots.
+    const auto publish4 = [&](uint32_t wkeep, int npush) {
+        const unsigned long long b0 = __ballot((npush & 1) != 0), b1 = __ballot((npush & 2) != 0);
+        const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                           2 * (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+        int at = top + before;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (wkeep & (1u << c)) pool[at] = make_uint2(((uint32_t)ray << 26) | wch[c], __float_as_uint(wtn[c]));
+            at += (int)((wkeep >> c) & 1u);
+        }
+        top += __popcll(b0) + 2 * __popcll(b1);
+    };
     // The hot loop runs until the LDS part is empty with all workers idle, or too full for 64 more pushes; the
     // rare handling of both (refill from / spill to global memory) sits in the outer loop, outside the hot
     // loop's register allocation.
@@ -156,34 +202,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
             if (tent > limit) {
                 cur = COOP_NONE;
             } else if (W4 && !(cur & (1u << 25))) { // internal node of the 4-wide tree
-                // These boxes only cull (acceptance is the primitive's own test and its gate) and are padded beyond
-                // every primitive, so the slab test may take min/max instead of the reference's sign select: a ray
-                // lying exactly in a box plane (NaN from 0 * inf) cannot hit anything inside the padding anyway.
-                const float4 *n = sc.nodes4 + (size_t)cur * 8; // minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] child[4] -
-                const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5];
-                const float4 chf = n[6];
-                const float ax0[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ax1[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
-                const float ay0[4] = {mny.x, mny.y, mny.z, mny.w}, ay1[4] = {mxy.x, mxy.y, mxy.z, mxy.w};
-                const float az0[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, az1[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
-                wch[0] = __float_as_uint(chf.x); wch[1] = __float_as_uint(chf.y); wch[2] = __float_as_uint(chf.z); wch[3] = __float_as_uint(chf.w);
-                int nearest = -1;
-                float tnear = RTMI_FLT_MAX;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float x0 = (ax0[c] - W.o.x) * W.inv_d.x, x1 = (ax1[c] - W.o.x) * W.inv_d.x;
-                    const float y0 = (ay0[c] - W.o.y) * W.inv_d.y, y1 = (ay1[c] - W.o.y) * W.inv_d.y;
-                    const float z0 = (az0[c] - W.o.z) * W.inv_d.z, z1 = (az1[c] - W.o.z) * W.inv_d.z;
-                    const float tn = fmaxf(fmaxf(fmaxf(wqmin, fminf(x0, x1)), fminf(y0, y1)), fminf(z0, z1));
-                    const float tf = fminf(fminf(fminf(wqmax, fmaxf(x0, x1)), fmaxf(y0, y1)), fmaxf(z0, z1));
-                    wtn[c] = tn;
-                    // (the explicit test of the child word stays: a ray with NaN components passes every min/max slab
-                    // test, and an empty slot's reference must never reach the pool)
-                    const bool okc = tf > tn && !(tn > limit) && wch[c] != COOP_NONE;
-                    if (okc) wkeep |= 1u << c;
-                    if (okc && tn < tnear) { nearest = c; tnear = tn; }
-                }
-                if (nearest >= 0) { cur = wch[nearest]; tent = tnear; wkeep &= ~(1u << nearest); } else cur = COOP_NONE;
-                npush = __popc(wkeep); // what is left gets published
+                visit4(limit, wkeep, npush);
             } else if (!(cur & (1u << 25))) { // internal node
                 const float4 *n = sc.nodes + (size_t)cur * 4;
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
@@ -240,17 +259,8 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
             }
         }
         // ---- publish the far children
-        if (W4) { // exclusive prefix sum of the per-worker counts (0..3) from two ballots
-            const unsigned long long b0 = __ballot((npush & 1) != 0), b1 = __ballot((npush & 2) != 0);
-            const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
-                               2 * (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
-            int at = top + before;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (wkeep & (1u << c)) pool[at] = make_uint2(((uint32_t)ray << 26) | wch[c], __float_as_uint(wtn[c]));
-                at += (int)((wkeep >> c) & 1u);
-            }
-            top += __popcll(b0) + 2 * __popcll(b1);
+        if (W4) {
+            publish4(wkeep, npush);
         } else {
         const unsigned long long m_push = __ballot(push);
         if (push) {
