@@ -526,10 +526,15 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
         const uint32_t wide = 64u * (3u * s->meta.alt_max_depth + 2u);
         if (wide > P.spill_cap) P.spill_cap = wide;
     }
-    // the lean kernel (no gates, no spill code) serves scenes whose whole stack bound fits 768 LDS entries and
-    // that walk the reference trees; everything else takes the extended one with a 512-entry LDS part
-    const bool ext = P.use_alt || deepest > 10u || (p->flags & (1u << 11));
-    P.coop_cap = ext ? 512u : P.spill_cap;
+    // the lean kernel (no gates, no spill code) serves scenes without BVH items; everything else takes the extended
+    // one with a 512-entry LDS part
+    // (lean = scenes WITHOUT any BVH: its instantiation also carries the LDS word ring of the RNG, which pays exactly
+    // there, see rtmi_rng.hpp)
+    const bool ext = P.use_alt || s->meta.n_nodes != 0u || (p->flags & (1u << 11));
+#ifndef RTMI_COOP_CAP
+#define RTMI_COOP_CAP 512u
+#endif
+    P.coop_cap = ext ? RTMI_COOP_CAP : P.spill_cap;
     if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
     // persistent grid: as many wavefronts as the kernel instantiation keeps resident (4 SIMDs x its waves per SIMD)
     const uint32_t wps_req = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
@@ -544,7 +549,7 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
         }
     }
     P.spill = s->spill;
-    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u) * sizeof(uint32_t);
+    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u + (ext ? 0u : RTMI_RNG_RING_WORDS)) * sizeof(uint32_t);
     const uint32_t ntex = P.ntiles_local * 64u;
     uint32_t blocks_total = 0, chunks_total = 0;
     for (uint32_t s0 = 0; s0 < p->ns; s0 += pass_ns) { // one pass unless the sample buffer is smaller than ns samples

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
 
     uint32_t oidx = 0u, ltile = 0u; // slot of this lane's path in the per-sample buffer; its local tile (SIG only)
     bool alive = false, done = false, have_hit = false;
-    Rng g;
+    RngReg g;
     rng_init(g, 0, 0);
     Path pa;
     pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     const int wave = threadIdx.x >> 6;
     CoopWork cw;
     cw.cap = (int)P.coop_cap;
-    cw.wlds = lds_dyn + (size_t)wave * (2u * cw.cap + 64u * 12u + 128u);
+    cw.wlds = lds_dyn + (size_t)wave * (2u * cw.cap + 64u * 12u + 128u + (EXT ? 0u : RTMI_RNG_RING_WORDS));
     cw.spill_cap = (int)P.spill_cap;
     cw.spill = P.spill + (size_t)(blockIdx.x * WAVES_PER_BLOCK + wave) * P.spill_cap;
     unsigned long long sig = 0ull;
@@ -164,7 +164,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
 
     uint32_t oidx = 0u, ltile = 0u; // slot of this lane's path in the per-sample buffer; its local tile (SIG only)
     bool alive = false, done = false, have_hit = false, overflow = false;
-    Rng g;
+    // lean instantiation (scenes without alternative trees): word ring in LDS behind pool | ctx | best
+    typename std::conditional<EXT, RngReg, RngRing>::type g;
+    rng_attach(g, cw.wlds + 2u * cw.cap + 64u * 12u + 128u);
     rng_init(g, 0, 0);
     Path pa;
     pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
     const uint32_t s_end = in_image ? s_begin + w.total / w.n_valid : s_begin;
     const uint32_t px = w.x0 + (uint32_t)(lane & 7), j = P.ny - 1u - (w.y0 + (uint32_t)(lane >> 3));
     uint32_t s = s_begin;
-    Rng g;
+    RngReg g;
     rng_init(g, 0, 0);
     Path pa;
     pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;

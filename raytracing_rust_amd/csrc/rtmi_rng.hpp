@@ -2,16 +2,13 @@
 // Part of the single translation unit rtmi_device.hip (device code is header-only so that every
 // kernel instantiation inlines the whole path); arithmetic contract as stated there.
 #pragma once
+#include <type_traits>
+
 #include "rtmi_types.hpp"
 
 // ----------------------------------------------------------------------------------
 // Philox4x32-10; stream = (block, sample, pixel, 0) under key = seed
 // ----------------------------------------------------------------------------------
-struct Rng {
-    uint32_t block, sample, pixel;
-    uint32_t b0, b1, b2, b3;
-    uint32_t pos;
-};
 __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                        uint32_t &o0, uint32_t &o1, uint32_t &o2, uint32_t &o3) {
 #pragma unroll
@@ -28,11 +25,70 @@ __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, ui
     }
     o0 = c0; o1 = c1; o2 = c2; o3 = c3;
 }
-__device__ __forceinline__ void rng_init(Rng &g, uint32_t sample, uint32_t pixel) {
-    g.block = 0; g.sample = sample; g.pixel = pixel; g.pos = 4;
+// ---- RngRing ----------------------------------------------------------------------------------------------------
+// Stream state of one path: the next word to read (`rd`) and to generate (`wr`, a multiple of 4), both counted from
+// the start of the stream, and a ring of 8 words in LDS ([slot][lane] of the wavefront, conflict-free): up to two
+// Philox blocks buffered.  A lane that is short of words triggers an evaluation; EVERY lane of the active set that
+// has room for a block (<= 4 words buffered) generates its next one in that same evaluation.  With the 4-word
+// register buffer a single draw (fog, shutter time, Schlick) found "some lane at a block boundary" nearly every
+// time and evaluated Philox for the quarter of the lanes that were; now the lanes stay in phase and most single
+// draws find their word buffered.  Same stream, same words, same order.
+struct RngRing {
+    uint32_t sample, pixel;
+    uint32_t rd, wr;
+    uint32_t *ring; // LDS: this lane's column, stride 64 words between slots
+};
+#define RTMI_RNG_RING_WORDS 512 /* 8 slots x 64 lanes per wavefront */
+__device__ __forceinline__ void rng_attach(RngRing &g, uint32_t *wave_ring) { g.ring = wave_ring + (threadIdx.x & 63); }
+__device__ __forceinline__ void rng_init(RngRing &g, uint32_t sample, uint32_t pixel) {
+    g.sample = sample; g.pixel = pixel; g.rd = 0u; g.wr = 0u;
+}
+// all ACTIVE lanes call; afterwards every active lane holds at least n (<= 3) unread words
+__device__ __forceinline__ void rng_need(RngRing &g, uint32_t n, uint32_t k0, uint32_t k1) {
+    const uint32_t have = g.wr - g.rd;
+    if (__ballot(have < n) != 0ull) { // uniform over the active lanes
+        if (have <= 4u) {
+            uint32_t o0, o1, o2, o3;
+            philox(g.wr >> 2, g.sample, g.pixel, 0u, k0, k1, o0, o1, o2, o3);
+            uint32_t *w = g.ring + ((g.wr & 4u) << 6); // slots 0..3 or 4..7
+            w[0] = o0; w[64] = o1; w[128] = o2; w[192] = o3;
+            g.wr += 4u;
+        }
+    }
+}
+__device__ __forceinline__ uint32_t rng_word(RngRing &g) {
+    const uint32_t w = g.ring[(g.rd & 7u) << 6];
+    g.rd++;
+    return w;
 }
 // rng.gen::<f64>() of the reference (24-bit uniform, rtmi_u01)
-__device__ __forceinline__ float rng_uniform(Rng &g, uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ float rng_uniform(RngRing &g, uint32_t k0, uint32_t k1) {
+    rng_need(g, 1u, k0, k1);
+    return rtmi_u01(rng_word(g));
+}
+__device__ __forceinline__ void rng_take3(RngRing &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+    rng_need(g, 3u, k0, k1);
+    w0 = rng_word(g); w1 = rng_word(g); w2 = rng_word(g);
+}
+__device__ __forceinline__ void rng_take2(RngRing &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1) {
+    rng_need(g, 2u, k0, k1);
+    w0 = rng_word(g); w1 = rng_word(g);
+}
+// ---- RngReg: one 4-word block in registers ---------------------------------------------------------------------
+// Measured (r02): the ring wins wherever the kernel has no BVH to traverse (cornell_box +16 %, cornell_smoke +12 %,
+// two_spheres +23 %) and loses 2 % where it has (final_scene, random_spheres: a draw then waits for LDS inside the
+// long item loop); the cooperative kernel therefore takes RngRing in its lean instantiation and RngReg in the other.
+struct RngReg {
+    uint32_t block, sample, pixel;
+    uint32_t b0, b1, b2, b3;
+    uint32_t pos;
+};
+__device__ __forceinline__ void rng_init(RngReg &g, uint32_t sample, uint32_t pixel) {
+    g.block = 0; g.sample = sample; g.pixel = pixel; g.pos = 4;
+}
+__device__ __forceinline__ void rng_attach(RngReg &, uint32_t *) {}
+// rng.gen::<f64>() of the reference (24-bit uniform, rtmi_u01)
+__device__ __forceinline__ float rng_uniform(RngReg &g, uint32_t k0, uint32_t k1) {
     if (g.pos == 4) {
         philox(g.block, g.sample, g.pixel, 0u, k0, k1, g.b0, g.b1, g.b2, g.b3);
         g.block++;
@@ -47,7 +103,7 @@ __device__ __forceinline__ float rng_uniform(Rng &g, uint32_t k0, uint32_t k1) {
 // for the whole wavefront.  Calling rng_uniform three times evaluates Philox up to three times per
 // wavefront (lanes sit at different positions of their 4-word blocks, so at every call some lane
 // needs a refill and the others wait).  Same stream, same words, same order: bit-identical.
-__device__ __forceinline__ void rng_take3(Rng &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
+__device__ __forceinline__ void rng_take3(RngReg &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
     uint32_t n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
     const uint32_t pos = g.pos;
     if (pos >= 2u) { // fewer than three words left in the current block
@@ -60,7 +116,7 @@ __device__ __forceinline__ void rng_take3(Rng &g, uint32_t k0, uint32_t k1, uint
     if (pos >= 2u) { g.b0 = n0; g.b1 = n1; g.b2 = n2; g.b3 = n3; g.pos = pos - 1u; } // 2->1, 3->2, 4->3
     else g.pos = pos + 3u;
 }
-__device__ __forceinline__ void rng_take2(Rng &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1) {
+__device__ __forceinline__ void rng_take2(RngReg &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1) {
     uint32_t n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
     const uint32_t pos = g.pos;
     if (pos >= 3u) {
@@ -73,8 +129,10 @@ __device__ __forceinline__ void rng_take2(Rng &g, uint32_t k0, uint32_t k1, uint
     else g.pos = pos + 2u;
 }
 
+
 // src/util.rs:4-13 (draws x, y, z per trial)
-__device__ __forceinline__ F3 random_in_unit_sphere(Rng &g, uint32_t k0, uint32_t k1) {
+template <typename RngT>
+__device__ __forceinline__ F3 random_in_unit_sphere(RngT &g, uint32_t k0, uint32_t k1) {
     for (;;) {
         uint32_t w0, w1, w2;
         rng_take3(g, k0, k1, w0, w1, w2);
@@ -84,7 +142,8 @@ __device__ __forceinline__ F3 random_in_unit_sphere(Rng &g, uint32_t k0, uint32_
     }
 }
 // src/util.rs:15-24 (draws x, y per trial)
-__device__ __forceinline__ F3 random_in_unit_disk(Rng &g, uint32_t k0, uint32_t k1) {
+template <typename RngT>
+__device__ __forceinline__ F3 random_in_unit_disk(RngT &g, uint32_t k0, uint32_t k1) {
     for (;;) {
         uint32_t w0, w1;
         rng_take2(g, k0, k1, w0, w1);

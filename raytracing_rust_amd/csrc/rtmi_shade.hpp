@@ -232,7 +232,8 @@ struct Path { // one camera path in flight (per lane)
 };
 
 // next sample of this pixel: tests/test.rs:66-68 + Camera::get_ray (camera.rs:53-67)
-__device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevParams &P, Rng &g, uint32_t k0, uint32_t k1,
+template <typename RngT>
+__device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevParams &P, RngT &g, uint32_t k0, uint32_t k1,
                                               uint32_t s, uint32_t pixel, uint32_t px, uint32_t j, Path &pa) {
     rng_init(g, s, pixel);
     uint32_t wu, wv;
@@ -256,8 +257,9 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevPar
 // ConstantMedium::hit after both boundary queries — medium.rs:33-53.  Returns true when the
 // medium scatters before the boundary exit / the closest hit so far; the draw happens only when
 // the clamped interval is non-empty, as in the reference.
+template <typename RngT>
 __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, F3 world_d,
-                                              float neg_inv_density, Rng &g, uint32_t k0, uint32_t k1, float &t_out) {
+                                              float neg_inv_density, RngT &g, uint32_t k0, uint32_t k1, float &t_out) {
     if (t1 < t_min) t1 = t_min;
     if (t2 > closest) t2 = closest;
     if (t1 < t2) {
@@ -277,7 +279,8 @@ __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, f
 // ALL 64 lanes call this together (the texture lookup is a wavefront operation, tex_value_wave); lanes with
 // active = true hold a hit to shade.  Returns true when the lane's path continues (pa holds the scattered ray),
 // false when it ended (or the lane was not active).  `scratch`: 64 floats of LDS private to the wavefront.
-__device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth, uint32_t ext, Rng &g, uint32_t k0, uint32_t k1,
+template <typename RngT>
+__device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth, uint32_t ext, RngT &g, uint32_t k0, uint32_t k1,
                                           bool active, float closest, int best_item, int best_pf, bool best_medium, Path &pa,
                                           float *scratch) {
     F3 hp = f3(0, 0, 0), hn = f3(1, 0, 0);
