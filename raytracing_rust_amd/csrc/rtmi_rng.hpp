@@ -78,7 +78,9 @@ __device__ __forceinline__ void rng_take2(RngRing &g, uint32_t k0, uint32_t k1, 
 // Measured (r02): the ring wins wherever the kernel has no BVH to traverse (cornell_box +16 %, cornell_smoke +12 %,
 // two_spheres +23 %) and loses 2 % where it has (final_scene, random_spheres: a draw then waits for LDS inside the
 // long item loop — and a hybrid that keeps the register block and parks one prefetched block per lane in LDS, so that
-// draws never wait for LDS, loses 3 % there as well: what does not pay on those kernels is the joining itself);
+// draws never wait for LDS, loses 3 % there as well.  Counters of the ring on final_scene: VALU instructions +0.6 % —
+// the evaluations it saves on single draws are spent on new paths joining with empty buffers — LDS instructions
+// +52 %, issue-wait share +17 %, same clock);
 // the cooperative kernel therefore takes RngRing in its lean instantiation and RngReg in the other.
 struct RngReg {
     uint32_t block, sample, pixel;
