@@ -5,4 +5,4 @@ tools/gpu_profile.sh ${T}_C5 > gpurun_out/${T}_C5.log 2>&1
 tools/gpu_profile.sh ${T}_C2 --scene random_spheres --nx 1200 --ny 800 --spp 500 > gpurun_out/${T}_C2.log 2>&1
 tools/gpu_profile.sh ${T}_C3 --scene cornell_box --nx 800 --ny 800 --spp 1000 > gpurun_out/${T}_C3.log 2>&1
 tools/gpu_profile.sh ${T}_C4 --scene cornell_smoke --nx 800 --ny 800 --spp 1000 > gpurun_out/${T}_C4.log 2>&1
-tail -3 gpurun_out/${T}_C*.log
+for f in gpurun_out/${T}_C*.log; do tail -n 2 $f; done
