@@ -118,35 +118,46 @@ def _free_port():
 
 
 def launch_ranks(n, argv, timeout_s):
+    """Starts the n rank processes (one per GPU) as fresh children, relays rank 0's stdout (the JSON line) and returns
+    the exit code.  A rank that dies takes the others down at once (they would otherwise sit in a collective until its
+    time-out); only the exact PIDs started here are ever signalled."""
+    import tempfile
+
     port = _free_port()
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=None))
     deadline = time.time() + timeout_s
-    rc, out0 = 0, b""
+    rc = 0
     try:
-        # rank 0's stdout is one JSON line: read it to EOF (its pipe closes when it exits), then reap the others
-        left = max(1.0, deadline - time.time())
-        out0, _ = procs[0].communicate(timeout=left)
-        for p in procs[1:]:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while True:
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            if any(c not in (None, 0) for c in codes) or time.time() > deadline:
+                rc = 124 if time.time() > deadline else 1
+                break
+            time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:  # exactly the children started above, by PID
                 p.kill()
                 p.wait()
     for r, p in enumerate(procs):
-        if p.returncode != 0 and rc == 0:
-            rc = p.returncode if p.returncode and p.returncode > 0 else 1
+        if p.returncode != 0:
+            if rc in (0, 1) and p.returncode and p.returncode > 0:
+                rc = p.returncode
+            elif rc == 0:
+                rc = 1
             sys.stderr.write("bench.py: rank %d exited with code %s\n" % (r, p.returncode))
-    sys.stdout.write(out0.decode(errors="replace"))
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode(errors="replace"))
     sys.stdout.flush()
     return rc
 

@@ -205,3 +205,28 @@ def test_leaf_boxes_of_negative_radius_spheres_are_proper(host):
         for mn, mx, ref in ((n.lmin, n.lmax, n.left), (n.rmin, n.rmax, n.right)):
             if ref < 0:  # leaf children only: an internal child's box is the reference's own (bvh.rs:60-64), inverted or not
                 assert all(mn[k] < mx[k] for k in range(3)), "inverted leaf box for child %#x" % (ref & 0xffffffff)
+
+
+def test_render_multi_rejects_bad_arguments_without_a_device(host):
+    """rtmi_render_multi validates its arguments before it touches a device (CPU-only box: then fails loudly)."""
+    from raytracing_rust_amd import scenes
+
+    lib = abi.load_rtmi()
+    cam, world = scenes.build(host, "two_spheres", 16, 16)
+    sc = host.lower(world)
+    d = sc.desc()
+    c = cam.lower()
+    lin = np.zeros((16, 16, 3), np.float32)
+    dev = (C.c_int * 2)(0, 0)
+    p = default_params(16, 16, 1)
+    assert lib.rtmi_render_multi(C.byref(d), dev, 0, C.byref(c), C.byref(p), lin.ctypes.data, None, None) == 1   # no devices
+    assert lib.rtmi_render_multi(C.byref(d), None, 2, C.byref(c), C.byref(p), lin.ctypes.data, None, None) == 1  # NULL list
+    bad = default_params(16, 16, 1, tile_rank=1, tile_world=2)
+    assert lib.rtmi_render_multi(C.byref(d), dev, 2, C.byref(c), C.byref(bad), lin.ctypes.data, None, None) == 1
+    assert b"whole image" in lib.rtmi_last_error()
+    sig = default_params(16, 16, 1, flags=abi.RTMI_FLAG_PATH_SIG)
+    assert lib.rtmi_render_multi(C.byref(d), dev, 2, C.byref(c), C.byref(sig), lin.ctypes.data, None, None) == 1
+    if lib.rtmi_device_count() == 0:
+        assert lib.rtmi_render_multi(C.byref(d), dev, 2, C.byref(c), C.byref(p), lin.ctypes.data, None, None) == 3  # RTMI_ERR_DEVICE
+        assert b"no HIP device" in lib.rtmi_last_error()
+        assert lib.rtmi_scene_status(None, None) == 1

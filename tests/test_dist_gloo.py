@@ -104,7 +104,8 @@ def test_bench_self_launches_its_ranks_without_a_launcher():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
     assert "WORLD_SIZE" not in r.stderr, r.stderr  # the old failure: "--gpus 2 but WORLD_SIZE=1"
-    assert r.stderr.count("bench.py needs a GPU") == 2, r.stderr  # both ranks got as far as their own device check
+    # a rank got as far as its own device check (the launcher stops the other one as soon as the first has failed)
+    assert 1 <= r.stderr.count("bench.py needs a GPU") <= 2, r.stderr
     assert "rank 0 exited" in r.stderr or "rank 1 exited" in r.stderr
 
 
