@@ -105,29 +105,34 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
     // One visit of a node of the 4-wide tree held in `cur` (ray context W): tests the four child boxes, keeps the
     // nearest surviving child in `cur` / `tent`, marks the others in `wkeep` for publication.
     // These boxes only cull (acceptance is the primitive's own test and its gate) and are padded beyond every
-    // primitive, so the slab test may take min/max instead of the reference's sign select: a ray lying exactly in
-    // a box plane (NaN from 0 * inf) cannot hit anything inside the padding anyway.
+    // primitive, so the slab test need not follow the reference's operation order.
     const auto visit4 = [&](float limit, uint32_t &wkeep, int &npush) {
-        const float4 *n = sc.nodes4 + (size_t)cur * 8; // minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] child[4] -
-        const float4 mnx = n[0], mny = n[1], mnz = n[2], mxx = n[3], mxy = n[4], mxz = n[5];
-        const float4 chf = n[6];
-        const float ax0[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, ax1[4] = {mxx.x, mxx.y, mxx.z, mxx.w};
-        const float ay0[4] = {mny.x, mny.y, mny.z, mny.w}, ay1[4] = {mxy.x, mxy.y, mxy.z, mxy.w};
-        const float az0[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, az1[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+        // near / far plane of every slab picked by the sign of the ray direction (an index into the record, no
+        // min/max pair per axis and box; measured final_scene +1.7 %, random_spheres +2.7 %).  A NaN from 0 * inf on a plane
+        // the ray lies in is ignored by fmaxf / fminf: no constraint from that plane, which only culls less.
+        const uint32_t base = cur * 8u; // minx[4] miny[4] minz[4] maxx[4] maxy[4] maxz[4] child[4] -
+        const uint32_t sx = W.inv_d.x < 0.0f ? 3u : 0u, sy = W.inv_d.y < 0.0f ? 3u : 0u, sz = W.inv_d.z < 0.0f ? 3u : 0u;
+        const float4 nx4 = sc.nodes4[base + sx], fx4 = sc.nodes4[base + 3u - sx];
+        const float4 ny4 = sc.nodes4[base + 1u + sy], fy4 = sc.nodes4[base + 4u - sy];
+        const float4 nz4 = sc.nodes4[base + 2u + sz], fz4 = sc.nodes4[base + 5u - sz];
+        const float4 chf = sc.nodes4[base + 6u];
+        const float anx[4] = {nx4.x, nx4.y, nx4.z, nx4.w}, afx[4] = {fx4.x, fx4.y, fx4.z, fx4.w};
+        const float any_[4] = {ny4.x, ny4.y, ny4.z, ny4.w}, afy[4] = {fy4.x, fy4.y, fy4.z, fy4.w};
+        const float anz[4] = {nz4.x, nz4.y, nz4.z, nz4.w}, afz[4] = {fz4.x, fz4.y, fz4.z, fz4.w};
         wch[0] = __float_as_uint(chf.x); wch[1] = __float_as_uint(chf.y); wch[2] = __float_as_uint(chf.z); wch[3] = __float_as_uint(chf.w);
         int nearest = -1;
         float tnear = RTMI_FLT_MAX;
+        // the pruning limit joins the far side of the interval: "tn < tf and tn <= limit" becomes "tn <= min(tf, limit)",
+        // which also lets a zero-thickness overlap through — a superset, and these boxes only cull (+0.9 % / +1.2 %)
+        const float far0 = fminf(wqmax, limit);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const float x0 = (ax0[c] - W.o.x) * W.inv_d.x, x1 = (ax1[c] - W.o.x) * W.inv_d.x;
-            const float y0 = (ay0[c] - W.o.y) * W.inv_d.y, y1 = (ay1[c] - W.o.y) * W.inv_d.y;
-            const float z0 = (az0[c] - W.o.z) * W.inv_d.z, z1 = (az1[c] - W.o.z) * W.inv_d.z;
-            const float tn = fmaxf(fmaxf(fmaxf(wqmin, fminf(x0, x1)), fminf(y0, y1)), fminf(z0, z1));
-            const float tf = fminf(fminf(fminf(wqmax, fmaxf(x0, x1)), fmaxf(y0, y1)), fmaxf(z0, z1));
+            const float tn = fmaxf(fmaxf(fmaxf(wqmin, (anx[c] - W.o.x) * W.inv_d.x), (any_[c] - W.o.y) * W.inv_d.y), (anz[c] - W.o.z) * W.inv_d.z);
+            const float tf = fminf(fminf(fminf(far0, (afx[c] - W.o.x) * W.inv_d.x), (afy[c] - W.o.y) * W.inv_d.y), (afz[c] - W.o.z) * W.inv_d.z);
             wtn[c] = tn;
             // (the explicit test of the child word stays: a ray with NaN components passes every min/max slab
             // test, and an empty slot's reference must never reach the pool)
-            const bool okc = tf > tn && !(tn > limit) && wch[c] != COOP_NONE;
+            const bool okc = !(tn > tf) && wch[c] != COOP_NONE;
             if (okc) wkeep |= 1u << c;
             if (okc && tn < tnear) { nearest = c; tnear = tn; }
         }
