@@ -288,7 +288,8 @@ int rtmi_render_device(rtmi_scene *scene, const rtmi_camera *cam, const rtmi_ren
  * depth-first bound of the pool; this is the loud end of that argument for the asynchronous entry point. */
 int rtmi_scene_status(rtmi_scene *scene, uint32_t *overflows);
 
-/* Whole image on several GPUs of this process: the scene description is uploaded to every
+/* Whole image on several GPUs of this process — the triple loop of create_image (tests/test.rs:62-79), which the
+ * reference runs on one thread, split over devices: the scene description is uploaded to every
  * listed device, device i renders the tiles t with t % n_devices == i on its own stream (all devices run
  * concurrently), the tile-packed framebuffers are gathered on devices[0] — one ncclGather over xGMI
  * (rccl.h ncclGather) when the listed devices are distinct, plain device-to-device copies when a device is

@@ -265,7 +265,7 @@ __device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, boo
         }
         // ---- publish the far children
         if (W4) {
-            publish4(wkeep, npush);
+            if (__ballot(npush != 0) != 0ull) publish4(wkeep, npush); // leaf-only rounds publish nothing
         } else {
         const unsigned long long m_push = __ballot(push);
         if (push) {
