@@ -116,6 +116,15 @@ impl Image {
         buf.truncate(n);
         String::from_utf8(buf).expect("P3 text is ASCII")
     }
+
+    /// Streams the image to `path` without building the string: `binary` = false writes the P3 text of `to_ppm`
+    /// (what tests/test.rs:560 writes), true the 4x smaller P6 form.
+    pub fn write_ppm(&self, path: &str, binary: bool) -> Result<(), RtmiError> {
+        let c = std::ffi::CString::new(path)
+            .map_err(|_| RtmiError { code: RTMI_ERR_INVALID, message: "path contains a NUL byte".into() })?;
+        let rc = unsafe { rtmi_write_ppm(c.as_ptr(), self.nx as u32, self.ny as u32, self.rgb8.as_ptr(), if binary { 6 } else { 3 }) };
+        check(rc)
+    }
 }
 
 pub fn default_params(nx: usize, ny: usize, ns: usize, seed: u64) -> RtmiRenderParams {

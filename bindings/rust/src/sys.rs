@@ -284,6 +284,8 @@ extern "C" {
         out_rgb8: *mut u8,
     ) -> c_int;
     pub fn rtmi_ppm_p3(nx: u32, ny: u32, rgb8: *const u8, buf: *mut c_char, cap: usize) -> usize;
+    /// streaming writer: format 3 = the P3 text of `create_image`, 6 = binary P6
+    pub fn rtmi_write_ppm(path: *const c_char, nx: u32, ny: u32, rgb8: *const u8, format: c_int) -> c_int;
     pub fn rtmi_probe_math(op: c_int, x: *const f32, y: *const f32, out: *mut f32, n: u32) -> c_int;
     pub fn rtmi_probe_philox(ctr: *const u32, key: *const u32, out: *mut u32, n: u32) -> c_int;
     pub fn rtmi_probe_xform(

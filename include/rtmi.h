@@ -315,6 +315,11 @@ int rtmi_untile(const rtmi_render_params *p, const rtmi_texel *gathered, float *
  * when buf is NULL or cap is too small. */
 size_t rtmi_ppm_p3(uint32_t nx, uint32_t ny, const uint8_t *rgb8, char *buf, size_t cap);
 
+/* The same image written straight to a file in 1 MiB pieces, without the whole-image string of create_image
+ * (tests/test.rs:58 builds ~12 B per pixel in memory, :560 writes it): format 3 = the P3 text above, byte for byte;
+ * format 6 = binary PPM ("P6\n{nx} {ny}\n255\n" + ny*nx*3 bytes, 4x smaller).  Returns RTMI_OK or an error code. */
+int rtmi_write_ppm(const char *path, uint32_t nx, uint32_t ny, const uint8_t *rgb8, int format);
+
 /* Test hooks: evaluate pieces of the arithmetic contract ON THE DEVICE so that parity
  * tests can compare them bit-for-bit with a host evaluation of rtmi_math.h / Philox.
  * op: 0 rtmi_sinf(x), 1 rtmi_logf(x), 2 rtmi_atan2f(x,y), 3 rtmi_asinf(x), 4 x/y,

@@ -121,7 +121,7 @@ class Stats(C.Structure):
 # every entry point include/rtmi.h declares (tests check that the library exports them all)
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_local_tiles",
                 "rtmi_render_prepare", "rtmi_render_device", "rtmi_scene_status", "rtmi_render", "rtmi_render_multi", "rtmi_untile",
-                "rtmi_ppm_p3", "rtmi_probe_math", "rtmi_probe_philox", "rtmi_probe_xform"]
+                "rtmi_ppm_p3", "rtmi_write_ppm", "rtmi_probe_math", "rtmi_probe_philox", "rtmi_probe_xform"]
 
 _rtmi = None
 _host = None
@@ -160,6 +160,8 @@ def load_rtmi():
     lib.rtmi_untile.argtypes = [C.POINTER(RenderParams), vp, vp, vp]
     lib.rtmi_ppm_p3.restype = C.c_size_t
     lib.rtmi_ppm_p3.argtypes = [C.c_uint32, C.c_uint32, vp, vp, C.c_size_t]
+    lib.rtmi_write_ppm.restype = C.c_int
+    lib.rtmi_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp, C.c_int]
     lib.rtmi_probe_math.restype = C.c_int
     lib.rtmi_probe_math.argtypes = [C.c_int, vp, vp, vp, C.c_uint32]
     lib.rtmi_probe_philox.restype = C.c_int

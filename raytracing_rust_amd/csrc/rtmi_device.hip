@@ -990,6 +990,38 @@ extern "C" size_t rtmi_ppm_p3(uint32_t nx, uint32_t ny, const uint8_t *rgb8, cha
     return (size_t)(w - buf);
 }
 
+// streaming writer: P3 text identical to rtmi_ppm_p3, or binary P6
+extern "C" int rtmi_write_ppm(const char *path, uint32_t nx, uint32_t ny, const uint8_t *rgb8, int format) {
+    if (!path || !rgb8) return fail(RTMI_ERR_INVALID, "rtmi_write_ppm: path or rgb8 is NULL");
+    if (format != 3 && format != 6) return fail(RTMI_ERR_INVALID, "rtmi_write_ppm: format must be 3 (P3 text) or 6 (P6 binary)");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(RTMI_ERR_INVALID, "rtmi_write_ppm: cannot open the output file");
+    bool ok = fprintf(f, "P%d\n%u %u\n255\n", format, nx, ny) > 0;
+    const size_t total = (size_t)nx * ny * 3;
+    if (format == 6) {
+        ok = ok && fwrite(rgb8, 1, total, f) == total;
+    } else {
+        static const char digits[] = "0123456789";
+        std::vector<char> chunk((size_t)1 << 20);
+        const size_t per_chunk = chunk.size() / 4; // <= 4 characters per value
+        for (size_t i0 = 0; ok && i0 < total; i0 += per_chunk) {
+            const size_t i1 = i0 + per_chunk < total ? i0 + per_chunk : total;
+            char *w = chunk.data();
+            for (size_t i = i0; i < i1; i++) {
+                const unsigned v = rgb8[i];
+                if (v >= 100) { *w++ = digits[v / 100]; *w++ = digits[(v / 10) % 10]; *w++ = digits[v % 10]; }
+                else if (v >= 10) { *w++ = digits[v / 10]; *w++ = digits[v % 10]; }
+                else { *w++ = digits[v]; }
+                *w++ = (i % 3 == 2) ? '\n' : ' ';
+            }
+            const size_t n = (size_t)(w - chunk.data());
+            ok = fwrite(chunk.data(), 1, n, f) == n;
+        }
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? RTMI_OK : fail(RTMI_ERR_INVALID, "rtmi_write_ppm: write failed");
+}
+
 // ---- probes (parity tests call these through the C ABI) ------------------------------
 extern "C" int rtmi_probe_math(int op, const float *x, const float *y, float *out, uint32_t n) {
     if (rtmi_device_count() <= 0) return fail(RTMI_ERR_DEVICE, "no HIP device available");

@@ -12,6 +12,7 @@ lowered to the flat scene of include/rtmi.h and rendered by the HIP kernels.  Th
 no CPU fallback for rendering: without the extension or without a GPU, render raises.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -386,3 +387,14 @@ def ppm_p3(rgb8):
     buf = C.create_string_buffer(need)
     n = lib.rtmi_ppm_p3(nx, ny, rgb8.ctypes.data, buf, need)
     return buf.raw[:n]
+
+
+def write_ppm(path, rgb8, fmt=3):
+    """Stream the image to `path` without building the whole-image string: fmt 3 = the P3 text of create_image
+    (byte-identical to ppm_p3), fmt 6 = binary P6."""
+    lib = abi.load_rtmi()
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    ny, nx = rgb8.shape[:2]
+    rc = lib.rtmi_write_ppm(os.fsencode(path), nx, ny, rgb8.ctypes.data, int(fmt))
+    if rc != 0:
+        raise HostError("rtmi_write_ppm failed (%d): %s" % (rc, lib.rtmi_last_error().decode()))

@@ -1073,6 +1073,9 @@ std::string Image::to_ppm() const {
     s.resize(rtmi_ppm_p3(nx, ny, rgb8.data(), s.data(), s.size()));
     return s;
 }
+void Image::write_ppm(const std::string &path, bool binary) const {
+    if (rtmi_write_ppm(path.c_str(), nx, ny, rgb8.data(), binary ? 6 : 3)) throw std::runtime_error(std::string("rtmi_write_ppm: ") + rtmi_last_error());
+}
 std::string create_image(size_t ny, size_t nx, size_t ns, const Camera &cam, const Hittable &world, const RenderOptions &opt) {
     return cam.render(world, (uint32_t)nx, (uint32_t)ny, (uint32_t)ns, opt).to_ppm();
 }

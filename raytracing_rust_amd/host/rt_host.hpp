@@ -391,6 +391,8 @@ struct Image {
     std::vector<uint8_t> rgb8;  // ny*nx*3
     rtmi_stats stats{};
     std::string to_ppm() const; // the String create_image returns (tests/test.rs:58-84)
+    // streamed to a file without that string: the same P3 text, or binary P6 (rtmi_write_ppm)
+    void write_ppm(const std::string &path, bool binary = false) const;
 };
 class Camera {
   public:

@@ -47,3 +47,25 @@ def test_native_ppm_writer_matches_create_image_format():
     assert hashlib.sha256(ppm_p3(rgb)).hexdigest() == GOLD
     rgb = np.array([[[0, 9, 10], [99, 100, 255]]], np.uint8)
     assert ppm_p3(rgb) == b"P3\n2 1\n255\n0 9 10\n99 100 255\n"
+
+
+def test_streaming_ppm_writer_p3_and_p6(tmp_path):
+    """rtmi_write_ppm: the P3 file is the create_image text byte for byte (golden sha on the
+    all-black 800x800 image; a random image spanning several 1 MiB pieces), P6 = header + the raw bytes."""
+    import numpy as np
+    import pytest
+
+    from raytracing_rust_amd import HostError, ppm_p3, write_ppm
+
+    p = str(tmp_path / "a.ppm")
+    write_ppm(p, np.zeros((800, 800, 3), np.uint8))
+    assert hashlib.sha256(open(p, "rb").read()).hexdigest() == GOLD
+    rgb = np.random.default_rng(3).integers(0, 256, (700, 901, 3), dtype=np.uint8)  # 1.9 M values, ~7 MB of text
+    write_ppm(p, rgb, 3)
+    assert open(p, "rb").read() == ppm_p3(rgb)
+    write_ppm(p, rgb, 6)
+    assert open(p, "rb").read() == b"P6\n901 700\n255\n" + rgb.tobytes()
+    with pytest.raises(HostError):
+        write_ppm(p, rgb, 5)
+    with pytest.raises(HostError):
+        write_ppm(str(tmp_path / "no_such_dir" / "a.ppm"), rgb)
