@@ -219,7 +219,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from raytracing_rust_amd import Host, abi, dist as rdist, ppm_p3, roofline, scenes
+    from raytracing_rust_amd import Host, abi, dist as rdist, roofline, scenes, write_ppm
 
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     if env_world != args.gpus:
@@ -306,11 +306,9 @@ def main():
     if rank == 0:
         g = gathered.cpu().numpy()
         lin, rgb = rdist.untile(params, g)
-        txt = ppm_p3(rgb)
-        with open(args.ppm_out, "wb") as f:
-            f.write(txt)
+        write_ppm(args.ppm_out, rgb, 3)  # the P3 text of create_image, streamed (rtmi_write_ppm)
         wall_ppm = time.perf_counter() - t1
-        checks = {"ppm_bytes": len(txt), "rgb_max": int(rgb.max()), "linear_mean": float(lin.mean())}
+        checks = {"ppm_bytes": os.path.getsize(args.ppm_out), "rgb_max": int(rgb.max()), "linear_mean": float(lin.mean())}
     scene.check_status()
     fence()
 
