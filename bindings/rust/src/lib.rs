@@ -177,6 +177,43 @@ impl Drop for Scene {
 }
 
 
+/// A world resident on a list of GPUs of this process (rtmi_multi_create): lowered and uploaded once, then any number
+/// of camera views rendered from it — a render costs the kernels, ONE gather and the un-tiling, not the uploads.
+/// `Camera::render` with `RenderOptions::devices` is `DeviceScene::new(..)?.render(..)` for a single image.
+pub struct DeviceScene {
+    raw: *mut RtmiMulti,
+}
+
+impl DeviceScene {
+    pub fn new(world: &std::rc::Rc<desc::HittableDesc>, devices: &[i32]) -> Result<DeviceScene, RtmiError> {
+        let flat = lower::lower_world(world).map_err(|e| RtmiError { code: RTMI_ERR_UNSUPPORTED, message: format!("{:?}", e) })?;
+        DeviceScene::upload(&flat, devices)
+    }
+    pub fn upload(flat: &FlatScene, devices: &[i32]) -> Result<DeviceScene, RtmiError> {
+        let mut raw = std::ptr::null_mut();
+        // the description is only borrowed for the call: rtmi_multi_create copies it to every listed device
+        check(unsafe { rtmi_multi_create(&flat.desc(), devices.as_ptr(), devices.len() as u32, &mut raw) })?;
+        Ok(DeviceScene { raw })
+    }
+    /// allocate the per-sample buffers of renders with these parameters now instead of in the first render (optional)
+    pub fn prepare(&mut self, p: &RtmiRenderParams) -> Result<(), RtmiError> {
+        check(unsafe { rtmi_multi_prepare(self.raw, p) })
+    }
+    /// Blocking whole-image render over all devices of the handle (tile_rank / tile_world = 0 / 1).
+    pub fn render(&mut self, cam: &RtmiCamera, p: &RtmiRenderParams) -> Result<Image, RtmiError> {
+        let (nx, ny) = (p.nx as usize, p.ny as usize);
+        let mut img = Image { nx, ny, linear: vec![0.0; nx * ny * 3], rgb8: vec![0; nx * ny * 3], stats: RtmiStats::default() };
+        check(unsafe { rtmi_multi_render(self.raw, cam, p, img.linear.as_mut_ptr(), img.rgb8.as_mut_ptr(), &mut img.stats) })?;
+        Ok(img)
+    }
+}
+
+impl Drop for DeviceScene {
+    fn drop(&mut self) {
+        unsafe { rtmi_multi_destroy(self.raw) }
+    }
+}
+
 /// `Camera` of src/camera.rs:8-18, with the state `Camera::new` derives (camera.rs:21-51) in f64.
 pub struct Camera {
     pub origin: [f64; 3],
@@ -196,7 +233,7 @@ pub struct RenderOptions {
     pub max_depth: u32,
     pub t_min: f64,
     pub flags: u32,
-    /// empty = `device`; otherwise the GPUs of this process to split the image over (rtmi_render_multi)
+    /// empty = `device`; otherwise the GPUs of this process to split the image over (a `DeviceScene` for one image)
     pub devices: Vec<i32>,
     pub device: i32,
     /// called about every 50 ms with (work units done, total); return false to cancel (replaces progressbar.rs)
@@ -262,12 +299,9 @@ impl Camera {
         }
         let cam = self.lower();
         if !opt.devices.is_empty() {
-            let mut img = Image { nx, ny, linear: vec![0.0; nx * ny * 3], rgb8: vec![0; nx * ny * 3], stats: RtmiStats::default() };
-            check(unsafe {
-                rtmi_render_multi(&flat.desc(), opt.devices.as_ptr(), opt.devices.len() as u32, &cam, &p, img.linear.as_mut_ptr(),
-                                  img.rgb8.as_mut_ptr(), &mut img.stats)
-            })?;
-            return Ok(img);
+            // several GPUs of this process: tiles t % n, one gather.  Hosts that render more than one image keep the
+            // DeviceScene instead (uploads and buffers are then paid once, not per image).
+            return DeviceScene::upload(&flat, &opt.devices)?.render(&cam, &p);
         }
         Scene::upload(&flat, opt.device)?.render(&cam, &p)
     }

@@ -242,6 +242,12 @@ pub struct RtmiScene {
     _private: [u8; 0],
 }
 
+/// opaque persistent multi-device handle (rtmi.h: rtmi_multi)
+#[repr(C)]
+pub struct RtmiMulti {
+    _private: [u8; 0],
+}
+
 extern "C" {
     pub fn rtmi_device_count() -> c_int;
     pub fn rtmi_last_error() -> *const c_char;
@@ -268,6 +274,17 @@ extern "C" {
         out_rgb8: *mut u8,
         stats: *mut RtmiStats,
     ) -> c_int;
+    pub fn rtmi_multi_create(desc: *const RtmiSceneDesc, devices: *const c_int, n_devices: u32, out: *mut *mut RtmiMulti) -> c_int;
+    pub fn rtmi_multi_prepare(m: *mut RtmiMulti, p: *const RtmiRenderParams) -> c_int;
+    pub fn rtmi_multi_render(
+        m: *mut RtmiMulti,
+        cam: *const RtmiCamera,
+        p: *const RtmiRenderParams,
+        out_linear_rgb: *mut f32,
+        out_rgb8: *mut u8,
+        stats: *mut RtmiStats,
+    ) -> c_int;
+    pub fn rtmi_multi_destroy(m: *mut RtmiMulti);
     pub fn rtmi_render(
         scene: *mut RtmiScene,
         cam: *const RtmiCamera,

@@ -13,7 +13,13 @@
  * Conventions: plain pointers and sizes only; inputs are borrowed for the duration of
  * the call; outputs are caller-allocated; every entry point returns 0 on success or an
  * RTMI_ERR_* code (message via rtmi_last_error()); nothing throws across the boundary.
- * A scene handle is immutable after creation and is bound to one device.
+ * Thread model.  A scene handle (rtmi_scene: one device; rtmi_multi: a device list) owns the device copy of the
+ * scene — read-only after creation — AND the scratch its render calls work in (unit queue and status words, the
+ * per-sample radiance buffer, f64 sums, the cached texel / signature buffers of the blocking calls).  Render calls on
+ * ONE handle therefore serialise: on the host by a per-handle mutex, on the device by an event chain (a render
+ * enqueued on any stream starts after the previous render of that handle has finished).  Any number of threads may
+ * call into one handle; each gets the image a single thread would get.  Different handles — also on the same device —
+ * are independent and render concurrently.  The reference's convention being replaced: one thread, Rc (bvh.rs:11-12).
  *
  * Arithmetic: fp32 on the device under the contract written in DESIGN.md ("fp32
  * arithmetic contract"); transcendental functions are those of rtmi_math.h; random
@@ -30,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 5u
+#define RTMI_ABI_VERSION 5u /* the scene description; entry points added since (rtmi_multi_*) do not change it */
 #define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
 #define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
 
@@ -288,7 +294,31 @@ int rtmi_render_device(rtmi_scene *scene, const rtmi_camera *cam, const rtmi_ren
  * depth-first bound of the pool; this is the loud end of that argument for the asynchronous entry point. */
 int rtmi_scene_status(rtmi_scene *scene, uint32_t *overflows);
 
-/* Whole image on several GPUs of this process — the triple loop of create_image (tests/test.rs:62-79), which the
+/* ---- several GPUs of this process behind one handle ("rtmi_scene_create copies ... to each selected
+ * device", multi-GPU internal to the render call) --------------------------------------------------------------------
+ * rtmi_multi_create uploads the description to every listed device (one host thread per device, so the uploads and
+ * the derived-record building overlap), makes the RCCL communicators when the listed devices are distinct, and
+ * returns a handle that keeps everything between calls: the device scenes, the per-device tile-packed framebuffers,
+ * the gathered framebuffer on devices[0] with its pinned host mirror, and — after the first render (or
+ * rtmi_multi_prepare) of a given size — the per-sample radiance buffers.  rtmi_multi_render then costs what the
+ * kernels, ONE gather and the un-tiling cost; it is what a host's Camera::render binds for create_image
+ * (tests/test.rs:55-85) with a device list.  devices[i] renders the tiles t with t % n_devices == i on its own stream,
+ * all devices concurrently; the gather onto devices[0] is one ncclGather over xGMI (rccl.h) when the listed devices
+ * are distinct, plain device-to-device copies when a device is listed more than once (single-GPU rehearsal: RCCL
+ * cannot put two ranks on one device).  The image is bit-identical to rtmi_render's for any device list.
+ * stats (optional): kernel_ms / render_ms = the slowest device's, samples = all devices'.
+ * params: tile_rank / tile_world must be 0 / 1; PATH_SIG and PROFILE are single-device diagnostics (rejected). */
+typedef struct rtmi_multi rtmi_multi;
+int rtmi_multi_create(const rtmi_scene_desc *desc, const int *devices, uint32_t n_devices, rtmi_multi **out);
+/* optional: allocate the per-sample buffers for renders with these params on every device now (idempotent) */
+int rtmi_multi_prepare(rtmi_multi *m, const rtmi_render_params *params);
+int rtmi_multi_render(rtmi_multi *m, const rtmi_camera *cam, const rtmi_render_params *params, float *out_linear_rgb,
+                      uint8_t *out_rgb8, rtmi_stats *stats);
+void rtmi_multi_destroy(rtmi_multi *m);
+
+/* One-shot form: rtmi_multi_create + rtmi_multi_render + rtmi_multi_destroy (pays the uploads and the allocations on
+ * every call; hosts that render more than once keep an rtmi_multi).
+ * Whole image on several GPUs of this process — the triple loop of create_image (tests/test.rs:62-79), which the
  * reference runs on one thread, split over devices: the scene description is uploaded to every
  * listed device, device i renders the tiles t with t % n_devices == i on its own stream (all devices run
  * concurrently), the tile-packed framebuffers are gathered on devices[0] — one ncclGather over xGMI

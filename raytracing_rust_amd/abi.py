@@ -120,7 +120,8 @@ class Stats(C.Structure):
 
 # every entry point include/rtmi.h declares (tests check that the library exports them all)
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_local_tiles",
-                "rtmi_render_prepare", "rtmi_render_device", "rtmi_scene_status", "rtmi_render", "rtmi_render_multi", "rtmi_untile",
+                "rtmi_render_prepare", "rtmi_render_device", "rtmi_scene_status", "rtmi_render", "rtmi_render_multi", "rtmi_multi_create",
+                "rtmi_multi_prepare", "rtmi_multi_render", "rtmi_multi_destroy", "rtmi_untile",
                 "rtmi_ppm_p3", "rtmi_write_ppm", "rtmi_probe_math", "rtmi_probe_philox", "rtmi_probe_xform"]
 
 _rtmi = None
@@ -154,6 +155,14 @@ def load_rtmi():
     lib.rtmi_render_multi.restype = C.c_int
     lib.rtmi_render_multi.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.POINTER(Camera), C.POINTER(RenderParams),
                                       vp, vp, C.POINTER(Stats)]
+    lib.rtmi_multi_create.restype = C.c_int
+    lib.rtmi_multi_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]
+    lib.rtmi_multi_prepare.restype = C.c_int
+    lib.rtmi_multi_prepare.argtypes = [vp, C.POINTER(RenderParams)]
+    lib.rtmi_multi_render.restype = C.c_int
+    lib.rtmi_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    lib.rtmi_multi_destroy.restype = None
+    lib.rtmi_multi_destroy.argtypes = [vp]
     lib.rtmi_render.restype = C.c_int
     lib.rtmi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
     lib.rtmi_untile.restype = C.c_int
@@ -222,6 +231,10 @@ def load_host():
         "rth_render_prepare": (i, [vp, C.POINTER(RenderParams)]),
         "rth_scene_status": (i, [vp]),
         "rth_render_multi": (i, [vp, vp, C.POINTER(RenderParams), C.POINTER(C.c_int), u32, vp, vp, C.POINTER(Stats)]),
+        "rth_upload_multi": (i, [vp, C.POINTER(C.c_int), u32]),
+        "rth_multi_free": (i, [vp]),
+        "rth_multi_prepare": (i, [vp, C.POINTER(RenderParams)]),
+        "rth_multi_render": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]),
         "rth_camera_render": (i, [vp, vp, u32, u32, u32, u64, u32, i, vp, vp, C.POINTER(Stats)]),
         "rth_hit": (i, [vp, vp, vp, d, d, d, u64, vp, vp]),
         "rth_bounding_box": (i, [vp, d, d, vp, vp]),

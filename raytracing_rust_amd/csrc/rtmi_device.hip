@@ -25,6 +25,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -67,8 +68,16 @@ struct rtmi_scene {
     size_t texel_count = 0;
     unsigned long long *d_sig = nullptr;
     size_t sig_count = 0;
-    std::vector<rtmi_texel> h_texels;
+    rtmi_texel *h_texels = nullptr;    // pinned host mirror of `texels` (hipHostMalloc: the D2H copy runs at link speed)
+    size_t h_texel_count = 0;
     std::vector<unsigned long long> h_sig;
+    // Thread model (rtmi.h): render calls on one handle serialise.  `mu` orders the host side (planning, scratch
+    // (re)allocation, enqueue, and for the blocking calls the wait and the copy-out); `busy` chains the device side: a
+    // render enqueued on ANY stream first waits for the previous render of this handle, whose kernels use the same
+    // unit queue, status words and per-sample buffer.
+    std::mutex mu;
+    hipEvent_t busy = nullptr;
+    bool busy_recorded = false;
     hipStream_t stream = nullptr;      // launches of the blocking API (non-blocking stream)
     hipStream_t copy_stream = nullptr; // progress polls while a launch runs
     uint64_t units_total = 0;          // work units of the last enqueued call (progress denominator)
@@ -340,6 +349,10 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
             rtmi_scene_destroy(s);
             return fail(RTMI_ERR_DEVICE, "hipEventCreate failed");
         }
+    if (hipEventCreateWithFlags(&s->busy, hipEventDisableTiming) != hipSuccess) {
+        rtmi_scene_destroy(s);
+        return fail(RTMI_ERR_DEVICE, "hipEventCreate failed");
+    }
     *out = s;
     return RTMI_OK;
 }
@@ -354,6 +367,8 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (s->texels) (void)hipFree(s->texels);
     if (s->d_sig) (void)hipFree(s->d_sig);
     if (s->status) (void)hipFree(s->status);
+    if (s->h_texels) (void)hipHostFree(s->h_texels);
+    if (s->busy) (void)hipEventDestroy(s->busy);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
     for (int i = 0; i < 3; i++)
@@ -440,20 +455,30 @@ extern "C" int rtmi_render_prepare(rtmi_scene *s, const rtmi_render_params *p) {
     if (!s) return fail(RTMI_ERR_INVALID, "NULL argument");
     int rc = check_params(p);
     if (rc) return rc;
+    std::lock_guard<std::mutex> lock(s->mu);
     HIP_TRY(hipSetDevice(s->device));
     const uint32_t ntiles_local = local_tiles_of(p, p->tile_rank);
     if (ntiles_local == 0) return RTMI_OK;
+    if (s->busy_recorded) HIP_TRY(hipEventSynchronize(s->busy)); // the buffer may be reallocated: no render may still use it
     uint32_t chunk_spp = 0, pass_ns = 0;
     return plan_and_reserve(s, p, ntiles_local, chunk_spp, pass_ns);
 }
 
-extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p, void *d_texels,
-                                  void *stream_, rtmi_stats *stats) {
+// the enqueue itself; the caller holds s->mu
+static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p, void *d_texels,
+                                void *stream_, rtmi_stats *stats) {
     if (!s || !cam || !d_texels) return fail(RTMI_ERR_INVALID, "NULL argument");
     int rc = check_params(p);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    // device side of the thread model: this render starts after the previous one of this handle has finished (a no-op
+    // when both were given the same stream)
+    if (s->busy_recorded) HIP_TRY(hipStreamWaitEvent(stream, s->busy, 0));
+    struct BusyMark { // records the end of this call's work on every return path after the first enqueue
+        rtmi_scene *s; hipStream_t st;
+        ~BusyMark() { if (hipEventRecord(s->busy, st) == hipSuccess) s->busy_recorded = true; }
+    } busy_mark{s, stream};
 
     DevParams P{};
     P.nx = p->nx; P.ny = p->ny; P.ns = p->ns; P.max_depth = p->max_depth; P.t_min = p->t_min;
@@ -633,8 +658,16 @@ extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const r
     return RTMI_OK;
 }
 
+extern "C" int rtmi_render_device(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p, void *d_texels,
+                                  void *stream_, rtmi_stats *stats) {
+    if (!s) return fail(RTMI_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lock(s->mu);
+    return render_device_locked(s, cam, p, d_texels, stream_, stats);
+}
+
 extern "C" int rtmi_scene_status(rtmi_scene *s, uint32_t *overflows) {
     if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
+    std::lock_guard<std::mutex> lock(s->mu);
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     unsigned int st = 0;
@@ -758,12 +791,22 @@ static void fill_stats(rtmi_scene *s, const rtmi_render_params *p, rtmi_stats *s
     (void)s;
 }
 
+// pinned host mirror of a texel buffer (grow-only)
+static int ensure_host_texels(rtmi_texel **h, size_t *have, size_t want) {
+    if (want <= *have) return RTMI_OK;
+    if (*h) { HIP_TRY(hipHostFree(*h)); *h = nullptr; *have = 0; }
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(h), want * sizeof(rtmi_texel), hipHostMallocDefault));
+    *have = want;
+    return RTMI_OK;
+}
+
 extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p_in, float *out_linear,
                            uint8_t *out_rgb8, uint64_t *out_path_sig, rtmi_stats *stats) {
     if (!s) return fail(RTMI_ERR_INVALID, "scene is NULL");
     int rc = check_params(p_in);
     if (rc) return rc;
     if (p_in->tile_world != 1) return fail(RTMI_ERR_INVALID, "rtmi_render renders the whole image: tile_world must be 1");
+    std::lock_guard<std::mutex> lock(s->mu); // the whole call: it works in the handle's texel / signature buffers
     HIP_TRY(hipSetDevice(s->device));
     if ((rc = ensure_streams(s))) return rc;
     rtmi_render_params p = *p_in;
@@ -773,6 +816,7 @@ extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_ren
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->texels), ntex * sizeof(rtmi_texel)));
         s->texel_count = ntex;
     }
+    if ((rc = ensure_host_texels(&s->h_texels, &s->h_texel_count, ntex))) return rc;
     p.flags &= ~RTMI_FLAG_PATH_SIG;
     p.path_sig = 0;
     if (out_path_sig) {
@@ -787,7 +831,7 @@ extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_ren
     if (p.progress_fn) {
         // asynchronous launch, then wait and report progress; stats from the scene's events afterwards
         HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-        rc = rtmi_render_device(s, cam, &p, s->texels, s->stream, nullptr);
+        rc = render_device_locked(s, cam, &p, s->texels, s->stream, nullptr);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(s->ev[2], s->stream));
         rtmi_scene *one[1] = {s};
@@ -801,11 +845,10 @@ extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_ren
         }
     } else {
         rtmi_stats local{};
-        rc = rtmi_render_device(s, cam, &p, s->texels, s->stream, stats ? stats : &local);
+        rc = render_device_locked(s, cam, &p, s->texels, s->stream, stats ? stats : &local);
         if (rc) return rc;
     }
-    s->h_texels.resize(ntex);
-    HIP_TRY(hipMemcpy(s->h_texels.data(), s->texels, ntex * sizeof(rtmi_texel), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(s->h_texels, s->texels, ntex * sizeof(rtmi_texel), hipMemcpyDeviceToHost));
     if (out_path_sig) {
         s->h_sig.resize(ntex);
         HIP_TRY(hipMemcpy(s->h_sig.data(), s->d_sig, ntex * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -816,10 +859,10 @@ extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_ren
                 out_path_sig[(size_t)row * p.nx + px] = s->h_sig[(size_t)t * 64 + (row % RTMI_TILE) * RTMI_TILE + px % RTMI_TILE];
             }
     }
-    return rtmi_untile(&p, s->h_texels.data(), out_linear, out_rgb8);
+    return rtmi_untile(&p, s->h_texels, out_linear, out_rgb8);
 }
 
-// ---- several GPUs of this process: scene replicated, tiles t % n, one gather on devices[0] --------------------
+// ---- several GPUs of this process behind one handle: scene replicated, tiles t % n, one gather on devices[0] -----
 // RCCL is bound lazily (dlopen) so that single-GPU users of librtmi.so do not load it; inside a PyTorch process the
 // soname resolves to the copy torch already mapped.
 namespace {
@@ -863,21 +906,191 @@ std::map<std::vector<int>, std::vector<void *>> g_comms; // one communicator set
         if (r_ != 0) return fail(RTMI_ERR_DEVICE, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));     \
     } while (0)
 
-namespace {
-struct MultiState { // frees what rtmi_render_multi created, on every return path
-    std::vector<rtmi_scene *> scenes;
-    std::vector<rtmi_texel *> texels;
+// The persistent multi-device handle.  Everything a render needs between calls lives here; rtmi_multi_render only
+// enqueues kernels and the one gather, waits, copies the gathered framebuffer out and un-tiles it.
+struct rtmi_multi {
     std::vector<int> devices;
-    rtmi_texel *gathered = nullptr;
-    ~MultiState() {
-        for (size_t i = 0; i < texels.size(); i++)
-            if (texels[i]) { (void)hipSetDevice(devices[i]); (void)hipFree(texels[i]); }
-        if (gathered) { (void)hipSetDevice(devices[0]); (void)hipFree(gathered); }
-        for (rtmi_scene *s : scenes) rtmi_scene_destroy(s);
-    }
+    bool distinct = true;
+    std::vector<rtmi_scene *> scenes;    // one per listed device (a device listed twice holds two scenes)
+    std::vector<rtmi_texel *> texels;    // per device: tile-packed local framebuffer (grow-only)
+    size_t stride = 0;                   // texels per rank in those buffers and in `gathered`
+    rtmi_texel *gathered = nullptr;      // on devices[0]: n x stride texels, rank-major
+    rtmi_texel *h_gathered = nullptr;    // its pinned host mirror
+    size_t h_count = 0;
+    std::vector<void *> comms;           // RCCL communicators (distinct devices, n > 1), made at create
+    std::mutex mu;                       // render calls on one handle serialise (rtmi.h, thread model)
 };
-} // namespace
 
+extern "C" void rtmi_multi_destroy(rtmi_multi *m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->texels.size(); i++)
+        if (m->texels[i]) { (void)hipSetDevice(m->devices[i]); (void)hipFree(m->texels[i]); }
+    if (m->gathered) { (void)hipSetDevice(m->devices[0]); (void)hipFree(m->gathered); }
+    if (m->h_gathered) (void)hipHostFree(m->h_gathered);
+    for (rtmi_scene *s : m->scenes) rtmi_scene_destroy(s);
+    delete m; // the communicators stay cached per device list for the process lifetime (g_comms)
+}
+
+extern "C" int rtmi_multi_create(const rtmi_scene_desc *desc, const int *devices, uint32_t n, rtmi_multi **out) {
+    if (!out) return fail(RTMI_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!desc || !devices || n == 0) return fail(RTMI_ERR_INVALID, "NULL argument or empty device list");
+    int rc = validate(desc);
+    if (rc) return rc;
+    const int ndev = rtmi_device_count();
+    if (ndev <= 0) return fail(RTMI_ERR_DEVICE, "no HIP device available (the rtmi path has no CPU fallback)");
+    rtmi_multi *m = new (std::nothrow) rtmi_multi();
+    if (!m) return fail(RTMI_ERR_NOMEM, "out of host memory");
+    struct Guard { rtmi_multi *m; ~Guard() { if (m) rtmi_multi_destroy(m); } } guard{m};
+    for (uint32_t i = 0; i < n; i++) {
+        if (devices[i] < 0 || devices[i] >= ndev) return fail(RTMI_ERR_INVALID, "device index out of range");
+        for (uint32_t k = 0; k < i; k++) m->distinct = m->distinct && devices[k] != devices[i];
+    }
+    m->devices.assign(devices, devices + n);
+    m->scenes.assign(n, nullptr);
+    m->texels.assign(n, nullptr);
+    // uploads to all devices at once: one host thread per device (hipMalloc / hipMemcpy of one device do not wait for
+    // another's; the derived records — leaf, shading, pool-encoded nodes — are built per thread as well)
+    std::vector<int> rcs(n, RTMI_OK);
+    std::vector<std::string> errs(n);
+    {
+        std::vector<std::thread> th;
+        for (uint32_t i = 0; i < n; i++)
+            th.emplace_back([&, i]() {
+                rcs[i] = rtmi_scene_create(desc, devices[i], &m->scenes[i]);
+                if (rcs[i] == RTMI_OK) {
+                    (void)hipSetDevice(devices[i]);
+                    rcs[i] = ensure_streams(m->scenes[i]);
+                }
+                if (rcs[i] != RTMI_OK) errs[i] = g_err; // g_err is thread-local
+            });
+        for (std::thread &t : th) t.join();
+    }
+    for (uint32_t i = 0; i < n; i++)
+        if (rcs[i] != RTMI_OK) return fail(rcs[i], "device " + std::to_string(devices[i]) + ": " + errs[i]);
+    if (m->distinct && n > 1) { // communicators at create, not in the first render
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        if (!g_rccl.load()) return fail(RTMI_ERR_DEVICE, g_rccl.err);
+        auto it = g_comms.find(m->devices);
+        if (it == g_comms.end()) {
+            std::vector<void *> c(n, nullptr);
+            RCCL_TRY(g_rccl.CommInitAll(c.data(), (int)n, devices));
+            it = g_comms.emplace(m->devices, c).first;
+        }
+        m->comms = it->second;
+    }
+    guard.m = nullptr;
+    *out = m;
+    return RTMI_OK;
+}
+
+// whole-image parameters -> per-device parameters; validates what the multi-device entry points accept
+static int multi_params(const rtmi_multi *m, const rtmi_render_params *p_in, std::vector<rtmi_render_params> &params) {
+    int rc = check_params(p_in);
+    if (rc) return rc;
+    if (p_in->tile_world != 1 || p_in->tile_rank != 0)
+        return fail(RTMI_ERR_INVALID, "multi-device render calls render the whole image: tile_rank/tile_world must be 0/1");
+    if (p_in->flags & (RTMI_FLAG_PATH_SIG | RTMI_FLAG_PROFILE)) return fail(RTMI_ERR_INVALID, "PATH_SIG / PROFILE are single-device diagnostics");
+    const uint32_t n = (uint32_t)m->devices.size();
+    params.assign(n, *p_in);
+    for (uint32_t i = 0; i < n; i++) { params[i].tile_world = n; params[i].tile_rank = i; }
+    return RTMI_OK;
+}
+// framebuffers of a render of this size (grow-only); every rank padded to rank 0's size (the largest)
+static int multi_reserve_texels(rtmi_multi *m, const rtmi_render_params *p0) {
+    const uint32_t n = (uint32_t)m->devices.size();
+    const size_t stride = (size_t)local_tiles_of(p0, 0) * 64;
+    if (stride > m->stride) {
+        for (uint32_t i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(m->devices[i]));
+            if (m->texels[i]) { HIP_TRY(hipFree(m->texels[i])); m->texels[i] = nullptr; }
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->texels[i]), stride * sizeof(rtmi_texel)));
+            // ranks with fewer tiles than rank 0 never write their padding: zero it once
+            HIP_TRY(hipMemset(m->texels[i], 0, stride * sizeof(rtmi_texel)));
+        }
+        HIP_TRY(hipSetDevice(m->devices[0]));
+        if (m->gathered) { HIP_TRY(hipFree(m->gathered)); m->gathered = nullptr; }
+        m->stride = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->gathered), (size_t)n * stride * sizeof(rtmi_texel)));
+        m->stride = stride;
+    }
+    return ensure_host_texels(&m->h_gathered, &m->h_count, (size_t)n * m->stride);
+}
+
+extern "C" int rtmi_multi_prepare(rtmi_multi *m, const rtmi_render_params *p_in) {
+    if (!m) return fail(RTMI_ERR_INVALID, "NULL argument");
+    std::vector<rtmi_render_params> params;
+    int rc = multi_params(m, p_in, params);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(m->mu);
+    if ((rc = multi_reserve_texels(m, &params[0]))) return rc;
+    for (size_t i = 0; i < m->scenes.size(); i++)
+        if ((rc = rtmi_render_prepare(m->scenes[i], &params[i]))) return rc;
+    return RTMI_OK;
+}
+
+extern "C" int rtmi_multi_render(rtmi_multi *m, const rtmi_camera *cam, const rtmi_render_params *p_in, float *out_linear,
+                                 uint8_t *out_rgb8, rtmi_stats *stats) {
+    if (!m || !cam) return fail(RTMI_ERR_INVALID, "NULL argument");
+    std::vector<rtmi_render_params> params;
+    int rc = multi_params(m, p_in, params);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(m->mu);
+    const uint32_t n = (uint32_t)m->devices.size();
+    if ((rc = multi_reserve_texels(m, &params[0]))) return rc;
+    // rank-major layout of the gathered buffer uses THIS call's stride (the buffers may be larger from an earlier call)
+    const size_t stride = (size_t)local_tiles_of(&params[0], 0) * 64;
+    std::vector<hipEvent_t> done(n);
+    // every device renders its tiles on its own stream, all concurrently
+    for (uint32_t i = 0; i < n; i++) {
+        rtmi_scene *s = m->scenes[i];
+        std::lock_guard<std::mutex> slock(s->mu);
+        HIP_TRY(hipSetDevice(m->devices[i]));
+        HIP_TRY(hipEventRecord(s->ev[0], s->stream));
+        if ((rc = render_device_locked(s, cam, &params[i], m->texels[i], s->stream, nullptr))) return rc;
+        HIP_TRY(hipEventRecord(s->ev[1], s->stream));
+        done[i] = s->ev[2];
+    }
+    // the ONE exchange of the path: tile-packed framebuffers -> devices[0]
+    if (!m->comms.empty()) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (uint32_t i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(m->devices[i]));
+            RCCL_TRY(g_rccl.Gather(m->texels[i], i == 0 ? m->gathered : nullptr, stride * sizeof(rtmi_texel), /*ncclInt8*/ 0, 0, m->comms[i], m->scenes[i]->stream));
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+    } else {
+        for (uint32_t i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(m->devices[i]));
+            HIP_TRY(hipMemcpyPeerAsync(m->gathered + (size_t)i * stride, m->devices[0], m->texels[i], m->devices[i], stride * sizeof(rtmi_texel), m->scenes[i]->stream));
+        }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(m->devices[i]));
+        HIP_TRY(hipEventRecord(m->scenes[i]->ev[2], m->scenes[i]->stream));
+    }
+    if ((rc = wait_with_progress(m->scenes.data(), done.data(), n, p_in))) return rc;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    for (uint32_t i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(m->devices[i]));
+        if ((rc = check_overflow(m->scenes[i]))) return rc;
+        if (stats) {
+            float ms_r = 0.f, ms_all = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms_r, m->scenes[i]->ev[0], m->scenes[i]->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&ms_all, m->scenes[i]->ev[0], m->scenes[i]->ev[2]));
+            rtmi_stats one{};
+            fill_stats(m->scenes[i], &params[i], &one, ms_r, ms_all);
+            stats->samples += one.samples; stats->tiles += one.tiles;
+            if (one.render_ms > stats->render_ms) stats->render_ms = one.render_ms;
+            if (one.kernel_ms > stats->kernel_ms) stats->kernel_ms = one.kernel_ms;
+        }
+    }
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipMemcpy(m->h_gathered, m->gathered, (size_t)n * stride * sizeof(rtmi_texel), hipMemcpyDeviceToHost));
+    return rtmi_untile(&params[0], m->h_gathered, out_linear, out_rgb8);
+}
+
+// one-shot form: create + render + destroy (pays uploads, allocations and the communicator look-up on every call)
 extern "C" int rtmi_render_multi(const rtmi_scene_desc *desc, const int *devices, uint32_t n, const rtmi_camera *cam,
                                  const rtmi_render_params *p_in, float *out_linear, uint8_t *out_rgb8, rtmi_stats *stats) {
     if (!desc || !devices || !cam || n == 0) return fail(RTMI_ERR_INVALID, "NULL argument or empty device list");
@@ -886,90 +1099,13 @@ extern "C" int rtmi_render_multi(const rtmi_scene_desc *desc, const int *devices
     if (p_in->tile_world != 1 || p_in->tile_rank != 0)
         return fail(RTMI_ERR_INVALID, "rtmi_render_multi renders the whole image: tile_rank/tile_world must be 0/1");
     if (p_in->flags & (RTMI_FLAG_PATH_SIG | RTMI_FLAG_PROFILE)) return fail(RTMI_ERR_INVALID, "PATH_SIG / PROFILE are single-device diagnostics");
-    const int ndev = rtmi_device_count();
-    if (ndev <= 0) return fail(RTMI_ERR_DEVICE, "no HIP device available (the rtmi path has no CPU fallback)");
-    bool distinct = true;
-    for (uint32_t i = 0; i < n; i++) {
-        if (devices[i] < 0 || devices[i] >= ndev) return fail(RTMI_ERR_INVALID, "device index out of range");
-        for (uint32_t k = 0; k < i; k++) distinct = distinct && devices[k] != devices[i];
-    }
-    MultiState st;
-    st.devices.assign(devices, devices + n);
-    st.scenes.assign(n, nullptr);
-    st.texels.assign(n, nullptr);
-    std::vector<rtmi_render_params> params(n, *p_in);
-    params[0].tile_world = n; params[0].tile_rank = 0;
-    const size_t stride = (size_t)local_tiles_of(&params[0], 0) * 64; // every rank padded to rank 0's size (the largest)
-    std::vector<hipEvent_t> done(n);
-    for (uint32_t i = 0; i < n; i++) {
-        params[i].tile_world = n; params[i].tile_rank = i;
-        if ((rc = rtmi_scene_create(desc, devices[i], &st.scenes[i]))) return rc;
-        HIP_TRY(hipSetDevice(devices[i]));
-        if ((rc = ensure_streams(st.scenes[i]))) return rc;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st.texels[i]), stride * sizeof(rtmi_texel)));
-        HIP_TRY(hipMemsetAsync(st.texels[i], 0, stride * sizeof(rtmi_texel), st.scenes[i]->stream));
-        done[i] = st.scenes[i]->ev[2];
-    }
-    HIP_TRY(hipSetDevice(devices[0]));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&st.gathered), (size_t)n * stride * sizeof(rtmi_texel)));
-    std::vector<void *> comms;
-    if (distinct && n > 1) {
-        std::lock_guard<std::mutex> lock(g_rccl_mutex);
-        if (!g_rccl.load()) return fail(RTMI_ERR_DEVICE, g_rccl.err);
-        auto it = g_comms.find(st.devices);
-        if (it == g_comms.end()) {
-            std::vector<void *> c(n, nullptr);
-            RCCL_TRY(g_rccl.CommInitAll(c.data(), (int)n, devices));
-            it = g_comms.emplace(st.devices, c).first;
-        }
-        comms = it->second;
-    }
-    // every device renders its tiles on its own stream, all concurrently
-    for (uint32_t i = 0; i < n; i++) {
-        rtmi_scene *s = st.scenes[i];
-        HIP_TRY(hipSetDevice(devices[i]));
-        HIP_TRY(hipEventRecord(s->ev[0], s->stream));
-        if ((rc = rtmi_render_device(s, cam, &params[i], st.texels[i], s->stream, nullptr))) return rc;
-        HIP_TRY(hipEventRecord(s->ev[1], s->stream));
-    }
-    // the ONE exchange of the path: tile-packed framebuffers -> devices[0]
-    if (!comms.empty()) {
-        RCCL_TRY(g_rccl.GroupStart());
-        for (uint32_t i = 0; i < n; i++) {
-            HIP_TRY(hipSetDevice(devices[i]));
-            RCCL_TRY(g_rccl.Gather(st.texels[i], i == 0 ? st.gathered : nullptr, stride * sizeof(rtmi_texel), /*ncclInt8*/ 0, 0, comms[i], st.scenes[i]->stream));
-        }
-        RCCL_TRY(g_rccl.GroupEnd());
-    } else {
-        for (uint32_t i = 0; i < n; i++) {
-            HIP_TRY(hipSetDevice(devices[i]));
-            HIP_TRY(hipMemcpyPeerAsync(st.gathered + (size_t)i * stride, devices[0], st.texels[i], devices[i], stride * sizeof(rtmi_texel), st.scenes[i]->stream));
-        }
-    }
-    for (uint32_t i = 0; i < n; i++) {
-        HIP_TRY(hipSetDevice(devices[i]));
-        HIP_TRY(hipEventRecord(st.scenes[i]->ev[2], st.scenes[i]->stream));
-    }
-    if ((rc = wait_with_progress(st.scenes.data(), done.data(), n, p_in))) return rc;
-    if (stats) memset(stats, 0, sizeof(*stats));
-    for (uint32_t i = 0; i < n; i++) {
-        HIP_TRY(hipSetDevice(devices[i]));
-        if ((rc = check_overflow(st.scenes[i]))) return rc;
-        if (stats) {
-            float ms_r = 0.f, ms_all = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms_r, st.scenes[i]->ev[0], st.scenes[i]->ev[1]));
-            HIP_TRY(hipEventElapsedTime(&ms_all, st.scenes[i]->ev[0], st.scenes[i]->ev[2]));
-            rtmi_stats one{};
-            fill_stats(st.scenes[i], &params[i], &one, ms_r, ms_all);
-            stats->samples += one.samples; stats->tiles += one.tiles;
-            if (one.render_ms > stats->render_ms) stats->render_ms = one.render_ms;
-            if (one.kernel_ms > stats->kernel_ms) stats->kernel_ms = one.kernel_ms;
-        }
-    }
-    HIP_TRY(hipSetDevice(devices[0]));
-    std::vector<rtmi_texel> host((size_t)n * stride);
-    HIP_TRY(hipMemcpy(host.data(), st.gathered, host.size() * sizeof(rtmi_texel), hipMemcpyDeviceToHost));
-    return rtmi_untile(&params[0], host.data(), out_linear, out_rgb8);
+    rtmi_multi *m = nullptr;
+    if ((rc = rtmi_multi_create(desc, devices, n, &m))) return rc;
+    rc = rtmi_multi_render(m, cam, p_in, out_linear, out_rgb8, stats);
+    const std::string keep = g_err; // destroy must not lose the message
+    rtmi_multi_destroy(m);
+    if (rc) g_err = keep;
+    return rc;
 }
 
 // P3 writer — tests/test.rs:59,79

@@ -151,6 +151,32 @@ class Scene:
                                                          rgb.ctypes.data, C.byref(st)))
         return {"linear": lin, "rgb8": rgb, "stats": _stats(st)}
 
+    def upload_multi(self, devices):
+        """Keeps the scene resident on a list of GPUs of this process (rtmi_multi_create): uploads once; every later
+        render_resident() costs the kernels, one gather and the un-tiling.  A device may be listed more than once."""
+        dev = (C.c_int * len(devices))(*devices)
+        self.host._check(self.host.lib.rth_upload_multi(self.h, dev, len(devices)))
+        self.multi_devices = list(devices)
+        return self
+
+    def free_multi(self):
+        self.host._check(self.host.lib.rth_multi_free(self.h))
+        self.multi_devices = None
+        return self
+
+    def prepare_resident(self, nx, ny, ns, **kw):
+        p = default_params(nx, ny, ns, **kw)
+        self.host._check(self.host.lib.rth_multi_prepare(self.h, C.byref(p)))
+        return self
+
+    def render_resident(self, cam, nx, ny, ns, out=None, **kw):
+        """rtmi_multi_render on the device list of upload_multi().  `out` = (linear, rgb8) arrays to reuse."""
+        p = default_params(nx, ny, ns, **kw)
+        lin, rgb = out if out is not None else (np.zeros((ny, nx, 3), np.float32), np.zeros((ny, nx, 3), np.uint8))
+        st = abi.Stats()
+        self.host._check(self.host.lib.rth_multi_render(self.h, cam.h, C.byref(p), lin.ctypes.data, rgb.ctypes.data, C.byref(st)))
+        return {"linear": lin, "rgb8": rgb, "stats": _stats(st)}
+
     def check_status(self):
         """Raises if an asynchronous render_device() call since the last check overflowed its traversal pool."""
         self.host._check(self.host.lib.rth_scene_status(self.h))

@@ -1038,9 +1038,7 @@ static int progress_trampoline(uint64_t done, uint64_t total, void *user) {
     const auto *fn = static_cast<const std::function<bool(uint64_t, uint64_t)> *>(user);
     try { return (*fn)(done, total) ? 0 : 1; } catch (...) { return 1; } // nothing may unwind through the C ABI
 }
-Image Camera::render(const Hittable &world, uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt) const {
-    const LoweredScene ls = lower_scene(world);
-    const rtmi_scene_desc d = ls.desc();
+static rtmi_render_params make_params(uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt) {
     rtmi_render_params p{};
     p.nx = nx; p.ny = ny; p.ns = ns; p.max_depth = opt.max_depth; p.t_min = (float)opt.t_min; p.flags = opt.flags;
     p.seed = opt.seed; p.tile_rank = 0; p.tile_world = 1; p.spp_chunks = opt.spp_chunks;
@@ -1048,16 +1046,41 @@ Image Camera::render(const Hittable &world, uint32_t nx, uint32_t ny, uint32_t n
         p.progress_fn = (uint64_t)(uintptr_t)&progress_trampoline;
         p.progress_user = (uint64_t)(uintptr_t)&opt.progress;
     }
+    return p;
+}
+DeviceScene::DeviceScene(const Hittable &world, const std::vector<int> &devices) : devices_(devices) {
+    const LoweredScene ls = lower_scene(world);
+    const rtmi_scene_desc d = ls.desc(); // borrowed for the call: rtmi_multi_create copies it to every device
+    if (int rc = rtmi_multi_create(&d, devices_.data(), (uint32_t)devices_.size(), &handle_))
+        throw std::runtime_error(std::string("rtmi_multi_create: ") + rtmi_last_error() + " (code " + std::to_string(rc) + ")");
+}
+DeviceScene::~DeviceScene() { rtmi_multi_destroy(handle_); }
+void DeviceScene::prepare(uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt) {
+    const rtmi_render_params p = make_params(nx, ny, ns, opt);
+    if (rtmi_multi_prepare(handle_, &p)) throw std::runtime_error(std::string("rtmi_multi_prepare: ") + rtmi_last_error());
+}
+Image DeviceScene::render(const Camera &cam, uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt) {
+    const rtmi_render_params p = make_params(nx, ny, ns, opt);
+    const rtmi_camera c = cam.lower();
+    Image img;
+    img.nx = nx; img.ny = ny;
+    img.linear.resize((size_t)nx * ny * 3);
+    img.rgb8.resize((size_t)nx * ny * 3);
+    if (rtmi_multi_render(handle_, &c, &p, img.linear.data(), img.rgb8.data(), &img.stats))
+        throw std::runtime_error(std::string("rtmi_multi_render: ") + rtmi_last_error());
+    return img;
+}
+Image Camera::render(const Hittable &world, uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt) const {
+    if (!opt.devices.empty()) // several GPUs of this process: tiles t % n, one gather
+        return DeviceScene(world, opt.devices).render(*this, nx, ny, ns, opt);
+    const LoweredScene ls = lower_scene(world);
+    const rtmi_scene_desc d = ls.desc();
+    const rtmi_render_params p = make_params(nx, ny, ns, opt);
     const rtmi_camera c = lower();
     Image img;
     img.nx = nx; img.ny = ny;
     img.linear.resize((size_t)nx * ny * 3);
     img.rgb8.resize((size_t)nx * ny * 3);
-    if (!opt.devices.empty()) { // several GPUs of this process: tiles t % n, one gather (rtmi_render_multi)
-        if (rtmi_render_multi(&d, opt.devices.data(), (uint32_t)opt.devices.size(), &c, &p, img.linear.data(), img.rgb8.data(), &img.stats))
-            throw std::runtime_error(std::string("rtmi_render_multi: ") + rtmi_last_error());
-        return img;
-    }
     rtmi_scene *scene = nullptr;
     if (int rc = rtmi_scene_create(&d, opt.device, &scene))
         throw std::runtime_error(std::string("rtmi_scene_create: ") + rtmi_last_error() + " (code " + std::to_string(rc) + ")");

@@ -405,6 +405,25 @@ class Camera {
     Vec3 origin_, lower_left_corner_, horizontal_, vertical_, u_, v_;
     double time0_, time1_, lens_radius_;
 };
+// A world kept resident on a list of GPUs of this process (rtmi_multi_create / _render / _destroy): lowered and
+// uploaded once, then any number of Camera views rendered from it — every render costs the kernels, one gather and the
+// un-tiling, not the uploads.  Camera::render with RenderOptions::devices is DeviceScene(world, devices).render(...)
+// for a single image.  Not copyable; render() may be called from several threads (calls on one scene serialise).
+class DeviceScene {
+  public:
+    DeviceScene(const Hittable &world, const std::vector<int> &devices);
+    ~DeviceScene();
+    DeviceScene(const DeviceScene &) = delete;
+    DeviceScene &operator=(const DeviceScene &) = delete;
+    // allocates the per-sample buffers of renders of this size now instead of in the first render() (optional)
+    void prepare(uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt = {});
+    Image render(const Camera &cam, uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt = {});
+    const std::vector<int> &devices() const { return devices_; }
+
+  private:
+    std::vector<int> devices_;
+    rtmi_multi *handle_ = nullptr;
+};
 // tests/test.rs:55-85 — note the argument order (ny, nx, ns, cam, world)
 std::string create_image(size_t ny, size_t nx, size_t ns, const Camera &cam, const Hittable &world,
                          const RenderOptions &opt = {});

@@ -27,6 +27,7 @@ struct Obj {
     std::shared_ptr<Camera> cam;
     std::shared_ptr<LoweredScene> lowered;
     rtmi_scene *dev = nullptr;
+    rtmi_multi *multi = nullptr; // the lowered scene resident on a device list (rth_upload_multi)
 };
 std::mutex g_mu;
 std::vector<Obj *> g_objs;
@@ -85,6 +86,7 @@ RTH_API void rth_free_all(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (Obj *o : g_objs) {
         if (o->dev) rtmi_scene_destroy(o->dev);
+        if (o->multi) rtmi_multi_destroy(o->multi);
         delete o;
     }
     g_objs.clear();
@@ -266,6 +268,41 @@ RTH_API int rth_render_multi(void *lowered, void *cam, const rtmi_render_params 
         const rtmi_scene_desc d = LOW(lowered)->lowered->desc();
         const rtmi_camera c = CAM(cam).lower();
         if (rtmi_render_multi(&d, devices, n, &c, p, out_linear, out_rgb8, stats)) throw std::runtime_error(std::string("rtmi_render_multi: ") + rtmi_last_error());
+        return RTH_OK;
+    });
+}
+// the lowered scene resident on a list of GPUs of this process (rtmi_multi_create); replaces an earlier list
+RTH_API int rth_upload_multi(void *lowered, const int *devices, uint32_t n) {
+    return guard([&] {
+        Obj *o = LOW(lowered);
+        if (o->multi) { rtmi_multi_destroy(o->multi); o->multi = nullptr; }
+        const rtmi_scene_desc d = o->lowered->desc();
+        if (int rc = rtmi_multi_create(&d, devices, n, &o->multi)) throw std::runtime_error(std::string("rtmi_multi_create: ") + rtmi_last_error() + " (code " + std::to_string(rc) + ")");
+        return RTH_OK;
+    });
+}
+RTH_API int rth_multi_free(void *lowered) {
+    return guard([&] {
+        Obj *o = LOW(lowered);
+        if (o->multi) { rtmi_multi_destroy(o->multi); o->multi = nullptr; }
+        return RTH_OK;
+    });
+}
+RTH_API int rth_multi_prepare(void *lowered, const rtmi_render_params *p) {
+    return guard([&] {
+        Obj *o = LOW(lowered);
+        if (!o->multi) throw std::runtime_error("scene not resident on a device list: call rth_upload_multi first");
+        if (rtmi_multi_prepare(o->multi, p)) throw std::runtime_error(std::string("rtmi_multi_prepare: ") + rtmi_last_error());
+        return RTH_OK;
+    });
+}
+RTH_API int rth_multi_render(void *lowered, void *cam, const rtmi_render_params *p, float *out_linear, uint8_t *out_rgb8,
+                             rtmi_stats *stats) {
+    return guard([&] {
+        Obj *o = LOW(lowered);
+        if (!o->multi) throw std::runtime_error("scene not resident on a device list: call rth_upload_multi first");
+        const rtmi_camera c = CAM(cam).lower();
+        if (rtmi_multi_render(o->multi, &c, p, out_linear, out_rgb8, stats)) throw std::runtime_error(std::string("rtmi_multi_render: ") + rtmi_last_error());
         return RTH_OK;
     });
 }

@@ -1,0 +1,188 @@
+"""The persistent multi-device handle (rtmi_multi_create / _prepare / _render / _destroy, SURVEY §8(b): the scene is
+copied to each selected device ONCE, multi-GPU is internal to the render call) and the thread model of rtmi.h
+(render calls on one handle serialise: per-handle mutex on the host, event chain on the device).
+
+The loop the handle shards is create_image's (tests/test.rs:62-79); the reference's convention being replaced is a
+single thread holding Rc's (src/bvh.rs:11-12).  CPU tests cover argument validation, symbol export and the
+thread-locality of rtmi_last_error; the GPU tests compare with rtmi_render bit-for-bit."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+import scenes_extra
+from raytracing_rust_amd import abi
+from raytracing_rust_amd.host import HostError, default_params
+
+
+# ------------------------------------------------------------------------------------------------ CPU
+def test_multi_entry_points_validate_before_touching_a_device(host):
+    from raytracing_rust_amd import scenes
+
+    lib = abi.load_rtmi()
+    cam, world = scenes.build(host, "two_spheres", 16, 16)
+    d = host.lower(world).desc()
+    dev = (C.c_int * 2)(0, 0)
+    h = C.c_void_p()
+    assert lib.rtmi_multi_create(C.byref(d), dev, 0, C.byref(h)) == 1 and not h.value       # empty list
+    assert lib.rtmi_multi_create(C.byref(d), None, 2, C.byref(h)) == 1 and not h.value      # NULL list
+    assert lib.rtmi_multi_create(C.byref(d), dev, 2, None) == 1                             # NULL out
+    bad = abi.SceneDesc.from_buffer_copy(d)
+    bad.abi_version = 4
+    assert lib.rtmi_multi_create(C.byref(bad), dev, 2, C.byref(h)) == 1 and b"abi_version" in lib.rtmi_last_error()
+    p = default_params(16, 16, 1)
+    c = cam.lower()
+    assert lib.rtmi_multi_render(None, C.byref(c), C.byref(p), None, None, None) == 1
+    assert lib.rtmi_multi_prepare(None, C.byref(p)) == 1
+    lib.rtmi_multi_destroy(None)  # a no-op, like free(NULL)
+    if lib.rtmi_device_count() == 0:
+        assert lib.rtmi_multi_create(C.byref(d), dev, 2, C.byref(h)) == 3 and not h.value   # RTMI_ERR_DEVICE: no fallback
+        assert b"no HIP device" in lib.rtmi_last_error()
+
+
+def test_last_error_is_thread_local_and_untile_is_reentrant():
+    """Two host threads inside the library at once: each keeps its own error text (rtmi_last_error is thread-local)
+    and rtmi_untile, which works only on its arguments, gives every thread the single-thread result."""
+    lib = abi.load_rtmi()
+    nx, ny = 40, 24
+    p = default_params(nx, ny, 1)
+    ntex = lib.rtmi_local_tiles(C.byref(p)) * 64
+    rng = np.random.default_rng(5)
+    tex = rng.random((ntex, 4), dtype=np.float32)
+    tex.view(np.uint32)[:, 3] = rng.integers(0, 1 << 24, ntex, dtype=np.uint32)
+    ref_lin = np.zeros((ny, nx, 3), np.float32)
+    ref_rgb = np.zeros((ny, nx, 3), np.uint8)
+    assert lib.rtmi_untile(C.byref(p), tex.ctypes.data, ref_lin.ctypes.data, ref_rgb.ctypes.data) == 0
+    out = {}
+    start = threading.Barrier(2)
+
+    def good():
+        start.wait()
+        for _ in range(200):
+            lin = np.zeros((ny, nx, 3), np.float32)
+            rgb = np.zeros((ny, nx, 3), np.uint8)
+            assert lib.rtmi_untile(C.byref(p), tex.ctypes.data, lin.ctypes.data, rgb.ctypes.data) == 0
+            assert np.array_equal(lin, ref_lin) and np.array_equal(rgb, ref_rgb)
+        out["good"] = True
+
+    def bad():
+        start.wait()
+        q = default_params(nx, ny, 1, tile_rank=3, tile_world=2)
+        for _ in range(200):
+            assert lib.rtmi_untile(C.byref(q), tex.ctypes.data, None, None) == 1
+            assert b"tile_rank" in lib.rtmi_last_error()
+        out["bad"] = True
+
+    ts = [threading.Thread(target=good), threading.Thread(target=bad)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert out == {"good": True, "bad": True}
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_resident_scene_renders_like_rtmi_render(host, devices):
+    """One upload, several renders of different sizes and cameras from the same handle (buffers grow, then are
+    reused for a smaller image): every image == rtmi_render's, bit for bit; the one-shot rtmi_render_multi too."""
+    sc = None
+    try:
+        for k, (nx, ny, ns, seed) in enumerate([(100, 60, 12, 42), (160, 96, 6, 7), (50, 30, 20, 42)]):
+            cam, world = scenes_extra.build(host, "lit_final_scene", nx, ny, seed=1)
+            if sc is None:
+                sc = host.lower(world)
+                sc.upload(0)
+                sc.upload_multi(devices)
+            if k == 1:
+                sc.prepare_resident(nx, ny, ns, seed=seed, flags=abi.RTMI_FLAG_FAST_CULL)
+            one = sc.render(cam, nx, ny, ns, seed=seed, flags=abi.RTMI_FLAG_FAST_CULL)
+            res = sc.render_resident(cam, nx, ny, ns, seed=seed, flags=abi.RTMI_FLAG_FAST_CULL)
+            assert np.array_equal(res["linear"], one["linear"]) and np.array_equal(res["rgb8"], one["rgb8"]), (k, devices)
+            assert res["stats"]["samples"] == nx * ny * ns and res["stats"]["render_ms"] > 0
+            assert one["linear"].mean() > 0.01
+        shot = sc.render_multi(cam, nx, ny, ns, devices, seed=seed, flags=abi.RTMI_FLAG_FAST_CULL)
+        assert np.array_equal(shot["linear"], one["linear"])
+        with pytest.raises(HostError):  # whole-image calls only
+            sc.render_resident(cam, nx, ny, ns, tile_rank=1, tile_world=2)
+        with pytest.raises(HostError):
+            host.lower(world).upload_multi([0, 99])
+    finally:
+        if sc is not None:
+            sc.free_multi()
+
+
+@pytest.mark.gpu
+def test_two_threads_on_one_handle_each_get_the_single_thread_image(host):
+    """rtmi.h thread model: two host threads render on ONE rtmi_scene (and on ONE rtmi_multi) at the same time, with
+    different seeds and sizes; each must receive exactly the image a single thread gets (the handle's unit queue,
+    status words, per-sample buffer and texel buffers are shared scratch: without the per-handle serialisation units
+    are skipped or doubled).  ctypes releases the GIL during the calls, so the threads really overlap."""
+    jobs = [(96, 64, 16, 42), (64, 40, 24, 1234)]
+    cams = []
+    sc = None
+    for nx, ny, ns, seed in jobs:
+        cam, world = scenes_extra.build(host, "lit_final_scene", nx, ny, seed=1)
+        cams.append(cam)
+        if sc is None:
+            sc = host.lower(world)
+            sc.upload(0)
+            sc.upload_multi([0, 0])
+    try:
+        want = [sc.render(cams[k], nx, ny, ns, seed=seed, flags=abi.RTMI_FLAG_FAST_CULL)
+                for k, (nx, ny, ns, seed) in enumerate(jobs)]
+        for fn in (sc.render, sc.render_resident):
+            got, errs = {}, []
+            start = threading.Barrier(2)
+
+            def work(k):
+                try:
+                    nx, ny, ns, seed = jobs[k]
+                    start.wait()
+                    for rep in range(4):
+                        r = fn(cams[k], nx, ny, ns, seed=seed, flags=abi.RTMI_FLAG_FAST_CULL)
+                        assert np.array_equal(r["linear"], want[k]["linear"]), (fn.__name__, k, rep)
+                        assert np.array_equal(r["rgb8"], want[k]["rgb8"])
+                    got[k] = True
+                except BaseException as e:  # noqa: BLE001 — reported by the main thread
+                    errs.append(repr(e))
+                    try:
+                        start.abort()
+                    except Exception:
+                        pass
+
+            ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert not errs, errs
+            assert got == {0: True, 1: True}
+    finally:
+        sc.free_multi()
+
+
+@pytest.mark.gpu
+def test_render_device_on_two_streams_of_one_handle_serialises_on_the_device(host):
+    """The asynchronous entry point, two torch streams, one handle: the second launch must wait for the first on the
+    device (event chain) — both framebuffers equal the blocking render's."""
+    import torch
+
+    from raytracing_rust_amd import dist as rdist
+
+    nx, ny, ns = 128, 80, 32
+    cam, world = scenes_extra.build(host, "lit_final_scene", nx, ny, seed=1)
+    sc = host.lower(world)
+    sc.upload(0)
+    want = {s: sc.render(cam, nx, ny, ns, seed=s, flags=abi.RTMI_FLAG_FAST_CULL) for s in (42, 43)}
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    params = [rdist.rank_params(nx, ny, ns, 0, 1, seed=s, flags=abi.RTMI_FLAG_FAST_CULL) for s in (42, 43)]
+    bufs = [rdist.new_local_framebuffer(p, dev) for p in params]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in (0, 1):
+            sc.render_device(cam, params[k], bufs[k].data_ptr(), streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    sc.check_status()
+    for k, s in enumerate((42, 43)):
+        lin, rgb = rdist.untile(params[k], bufs[k].cpu().numpy()[None])
+        assert np.array_equal(lin, want[s]["linear"]) and np.array_equal(rgb, want[s]["rgb8"])
