@@ -86,10 +86,37 @@ def _allcore_worker(job):
     return len(rows) * a["nx"] * spp
 
 
-def cpu_sample_allcore(scene, nx, ny, spp, rows_per_worker, nproc):
-    """The same oracle on all host cores: `nproc` forked workers (scene built once per worker, not timed), each
+def host_core_counts():
+    """(cores the host reports, cores this process may actually use): os.cpu_count() next to the scheduler affinity
+    and the cgroup CPU quota (a container on a big host sees all its cores but is throttled to its share)."""
+    host = os.cpu_count() or 1
+    usable = host
+    try:
+        usable = min(usable, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    usable = min(usable, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    usable = min(usable, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return host, usable
+
+
+def cpu_sample_allcore(scene, nx, ny, rows_per_worker, nproc, target_s):
+    """The same oracle on all usable host cores: `nproc` forked workers (scene built once per worker, not timed), each
     rendering its own rows (the reference itself is single-threaded; this is the generous baseline of
-    BASELINE.md §3).  Must run BEFORE the process touches the GPU (fork)."""
+    BASELINE.md §3).  A short calibration batch sizes the timed batch for about `target_s` seconds of wall clock.
+    Must run BEFORE the process touches the GPU (fork).  Returns (samples, seconds, spp of the timed batch)."""
     import multiprocessing as mp
 
     from oracle import oracle as orc_mod
@@ -101,9 +128,13 @@ def cpu_sample_allcore(scene, nx, ny, spp, rows_per_worker, nproc):
     with ctx.Pool(nproc, initializer=_allcore_init, initargs=(scene, nx, ny)) as pool:
         pool.map(_allcore_worker, [(1, [0])] * nproc)  # every worker has built its scene
         t0 = time.perf_counter()
+        n_cal = sum(pool.map(_allcore_worker, [(4, rows[w::nproc]) for w in range(nproc)], chunksize=1))
+        rate = n_cal / (time.perf_counter() - t0)
+        spp = max(8, min(4096, int(target_s * rate / (total_rows * nx) + 0.5)))
+        t0 = time.perf_counter()
         n = sum(pool.map(_allcore_worker, [(spp, rows[w::nproc]) for w in range(nproc)], chunksize=1))
         dt = time.perf_counter() - t0
-    return n, dt
+    return n, dt, spp
 
 
 # ------------------------------------------------------------------------------------------------
@@ -162,6 +193,73 @@ def launch_ranks(n, argv, timeout_s):
     return rc
 
 
+def abi_multi_leg(devices, scene_name, nx, ny, ns, flags, steps, ppm_path, compare_single=False):
+    """The path a host's Camera::render binds for create_image (tests/test.rs:55-85) with a device list: ONE persistent
+    handle (rtmi_multi_create), then whole-image renders from it.  Reports, for the same handle, what creating it
+    costs, the first call (which allocates the per-sample buffers) and the steady state — each as wall clock from the
+    call to the finished PPM file (render + the one gather + D2H + un-tiling + P3 text + write) — and destroy.
+    compare_single: also times rtmi_render (the single-device blocking call) on its own handle the same way."""
+    import numpy as np
+
+    from raytracing_rust_amd import Host, scenes, write_ppm
+
+    host = Host()
+    t = time.perf_counter()
+    cam, world = scenes.build(host, scene_name, nx, ny, seed=1)
+    sc = host.lower(world)
+    t_lower = time.perf_counter() - t
+    out = (np.zeros((ny, nx, 3), np.float32), np.zeros((ny, nx, 3), np.uint8))
+    kw = dict(seed=42, flags=flags)
+
+    def to_ppm(fn):
+        t0 = time.perf_counter()
+        r = fn()
+        t1 = time.perf_counter()
+        write_ppm(ppm_path, r["rgb8"], 3)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t0, r
+
+    t = time.perf_counter()
+    sc.upload_multi(devices)
+    t_create = time.perf_counter() - t
+    call1, first, r = to_ppm(lambda: sc.render_resident(cam, nx, ny, ns, out=out, **kw))
+    calls, walls, kern = [], [], []
+    for _ in range(steps):
+        c, w, r = to_ppm(lambda: sc.render_resident(cam, nx, ny, ns, out=out, **kw))
+        calls.append(c); walls.append(w); kern.append(r["stats"]["kernel_ms"])
+    checks = {"rgb_max": int(r["rgb8"].max()), "linear_mean": float(r["linear"].mean()), "samples": r["stats"]["samples"]}
+    t = time.perf_counter()
+    sc.free_multi()
+    t_destroy = time.perf_counter() - t
+    res = {
+        "entry_points": "rtmi_multi_create / rtmi_multi_render / rtmi_multi_destroy", "devices": list(devices),
+        "workload": "%s %dx%dx%dspp" % (scene_name, nx, ny, ns), "steps": steps,
+        "lower_s": round(t_lower, 4), "create_s": round(t_create, 4), "destroy_s": round(t_destroy, 4),
+        "first_call_s": round(call1, 4), "first_call_to_ppm_s": round(first, 4),
+        "steady_call_s": round(float(np.mean(calls)), 4), "steady_to_ppm_s": round(float(np.mean(walls)), 4),
+        "steady_to_ppm_min_s": round(float(np.min(walls)), 4),
+        "steady_kernel_ms_slowest_device": round(float(np.mean(kern)), 3),
+        "steady_msamples_per_s": round(float(nx) * ny * ns / float(np.mean(calls)) / 1e6, 2),
+        "one_shot_fixed_cost_s": round(t_create + (call1 - float(np.mean(calls))) + t_destroy, 4),
+        "checks": checks,
+    }
+    if compare_single:
+        t = time.perf_counter()
+        sc.upload(devices[0])
+        t_up = time.perf_counter() - t
+        to_ppm(lambda: sc.render(cam, nx, ny, ns, out=out, **kw))
+        c1, w1 = [], []
+        for _ in range(steps):
+            c, w, r1 = to_ppm(lambda: sc.render(cam, nx, ny, ns, out=out, **kw))
+            c1.append(c); w1.append(w)
+        res["rtmi_render_same_device"] = {"upload_s": round(t_up, 4), "steady_call_s": round(float(np.mean(c1)), 4),
+                                          "steady_to_ppm_s": round(float(np.mean(w1)), 4),
+                                          "multi_over_single": round(float(np.mean(calls)) / float(np.mean(c1)), 4),
+                                          "image_equal": bool(np.array_equal(r1["rgb8"], r["rgb8"]))}
+    host.free_all()
+    return res
+
+
 def load_profile_summary(path, workload):
     """profiles/pmc_summary.json (tools/pmc_summary.py): per workload the HBM bytes and the SQ counter sums of
     one launch of the dominant kernel, from rocprofv3 --pmc passes committed under profiles/."""
@@ -195,8 +293,17 @@ def main():
     ap.add_argument("--ppm-out", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "rtmi_bench.ppm"))
     ap.add_argument("--sample-buffer-mb", type=int, default=0, help="per-sample buffer budget (0 = library default)")
     ap.add_argument("--profile-json", default=os.path.join(ROOT, "profiles", "pmc_summary.json"))
-    ap.add_argument("--cpu-allcore-procs", type=int, default=min(16, os.cpu_count() or 1),
-                    help="workers of the all-core CPU sample (0 = skip)")
+    ap.add_argument("--cpu-allcore-procs", type=int, default=-1,
+                    help="workers of the all-core CPU sample (-1 = every core this process may use: os.cpu_count() "
+                         "unless the scheduler affinity or the cgroup quota is smaller; 0 = skip)")
+    ap.add_argument("--cpu-allcore-seconds", type=float, default=12.0, help="wall-clock target of the all-core sample")
+    ap.add_argument("--abi-multi", default="auto",
+                    help="devices of the persistent C-ABI handle leg (rtmi_multi_*): 'auto' = [0] at N = 1 and all N "
+                         "devices (in a child process of rank 0, after the ranks have finished) at N > 1; 'off'; or a "
+                         "comma-separated device list")
+    ap.add_argument("--abi-multi-child", default="", help=argparse.SUPPRESS)  # internal: run only the handle leg
+    ap.add_argument("--abi-multi-steps", type=int, default=3)
+    ap.add_argument("--abi-multi-timeout", type=int, default=420, help="seconds the N > 1 child may take")
     ap.add_argument("--no-baseline-config", action="store_true",
                     help="N > 1: skip the extra strong-scaled run of BASELINE config C5 (final_scene x5000spp)")
     ap.add_argument("--launch-timeout", type=int, default=3000, help="seconds the self-launcher waits for its ranks")
@@ -206,14 +313,25 @@ def main():
         # no launcher: become one.  Nothing in this process has initialised the GPU (torch is not even imported).
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
 
+    if args.abi_multi_child:
+        # internal: the persistent-handle leg alone, in a fresh process (N > 1: rank 0 starts it once the ranks are done)
+        devs = [int(x) for x in args.abi_multi_child.split(",")]
+        print(json.dumps(abi_multi_leg(devs, args.scene, args.nx, args.ny, args.spp, args.flags, args.abi_multi_steps,
+                                       args.ppm_out + ".multi")), flush=True)
+        return
+
     allcore = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and args.cpu_allcore_procs > 1:
+    host_cores, usable_cores = host_core_counts()
+    nproc_all = args.cpu_allcore_procs if args.cpu_allcore_procs >= 0 else min(usable_cores, 256)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline and nproc_all > 1:
         # before anything initialises the GPU: the workers are forked
-        spp_all, rows_all = max(1, args.cpu_spp // 4), 8  # many thin rows per worker: balanced
-        n_all, dt_all = cpu_sample_allcore(args.scene, args.nx, args.ny, spp_all, rows_all, args.cpu_allcore_procs)
-        allcore = {"value": round(n_all / dt_all / 1e6, 5), "unit": "Msamples/s", "cores": args.cpu_allcore_procs,
-                   "sample": "%d rows x %d px x %d spp in %d forked workers (%.1f s)"
-                             % (rows_all * args.cpu_allcore_procs, args.nx, spp_all, args.cpu_allcore_procs, dt_all)}
+        rows_all = 8  # many thin rows per worker: balanced
+        n_all, dt_all, spp_all = cpu_sample_allcore(args.scene, args.nx, args.ny, rows_all, nproc_all, args.cpu_allcore_seconds)
+        allcore = {"value": round(n_all / dt_all / 1e6, 5), "unit": "Msamples/s", "cores": nproc_all,
+                   "host_cores": host_cores, "usable_cores": usable_cores, "workers": nproc_all,
+                   "sample": "%d rows x %d px x %d spp in %d forked workers (%.1f s); the host reports %d cores, this "
+                             "process may use %d"
+                             % (rows_all * nproc_all, args.nx, spp_all, nproc_all, dt_all, host_cores, usable_cores)}
 
     import numpy as np
     import torch
@@ -323,10 +441,37 @@ def main():
         scene.check_status()
         fence()
 
+    if world > 1:
+        dist.destroy_process_group()  # the ranks are done; rank 0 goes on alone
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
         return
+
+    # ---- the persistent C-ABI handle (rtmi_multi_*): N = 1 in this process on [0]; N > 1 in a fresh child of rank 0
+    # over all N devices, after the other ranks have finished (their processes exit; nothing else runs on the GPUs)
+    abi_multi = None
+    if args.abi_multi != "off":
+        devs = list(range(world)) if args.abi_multi == "auto" else [int(x) for x in args.abi_multi.split(",")]
+        try:
+            host.free_all()  # release this rank's scene and its per-sample buffer first
+            torch.cuda.empty_cache()
+            if world == 1:
+                abi_multi = abi_multi_leg(devs, args.scene, nx, ny, ns, args.flags, args.abi_multi_steps,
+                                          args.ppm_out + ".multi", compare_single=True)
+            else:
+                cmd = [sys.executable, os.path.abspath(__file__), "--abi-multi-child", ",".join(map(str, devs)),
+                       "--scene", args.scene, "--nx", str(nx), "--ny", str(ny), "--spp", str(ns), "--flags", str(args.flags),
+                       "--abi-multi-steps", str(args.abi_multi_steps), "--ppm-out", args.ppm_out]
+                env = {k: v for k, v in os.environ.items()
+                       if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.abi_multi_timeout)
+                if cp.returncode == 0:
+                    abi_multi = json.loads(cp.stdout.decode().strip().splitlines()[-1])
+                else:
+                    abi_multi = {"error": "child exited with code %d" % cp.returncode, "stderr_tail": cp.stderr.decode(errors="replace")[-600:]}
+        except subprocess.TimeoutExpired:
+            abi_multi = {"error": "child exceeded %d s and was killed" % args.abi_multi_timeout}
+        except Exception as e:  # the headline line must still be printed
+            abi_multi = {"error": repr(e)}
 
     total_samples = float(nx) * ny * ns
     value = total_samples * args.steps / elapsed / 1e6
@@ -360,6 +505,8 @@ def main():
     }
     if baseline_cfg is not None:
         out["baseline_config"] = baseline_cfg
+    if abi_multi is not None:
+        out["abi_multi"] = abi_multi
 
     # ---- roofline + cpu baseline (rank 0).  Operation counts come from a small pass of the instrumented oracle;
     # the TIMED baseline is the uninstrumented -march=native build (N = 1 only).
@@ -386,13 +533,22 @@ def main():
         "why": "scene < 2 MB is L2 resident; measured HBM traffic is < 1 % of peak: VALU issue under divergence binds",
     }
     if prof:
+        # Everything below comes from the rocprofv3 PMC passes COMMITTED under profiles/ (one launch of the same kernel
+        # and workload on an MI355X), not from this run: kept apart under `profiled`; only `traffic` (the contract's
+        # field) is repeated at the top level.
+        pf = {"source": prof.get("source"), "hbm_bytes_per_launch": prof.get("hbm_bytes_per_launch")}
         rl["traffic"] = prof.get("hbm_bytes_per_launch")
-        if rl["traffic"]:
-            rl["hbm_frac"] = round(rl["traffic"] / launch_s / 1e9 / roofline.HBM_PEAK_GBS, 6)
         sq = roofline.sq_fractions(prof)
         if sq:
-            rl.update(sq)  # issue_frac, lane_util, wait_frac of the profiled launch
-        rl["counters_from"] = prof.get("source")
+            pf.update(sq)  # issue_frac, lane_util, wait_frac, profiled_launch_ms
+            if pf.get("profiled_launch_ms") and pf.get("hbm_bytes_per_launch"):
+                pf["hbm_frac"] = round(pf["hbm_bytes_per_launch"] / (pf["profiled_launch_ms"] * 1e-3) / 1e9 / roofline.HBM_PEAK_GBS, 6)
+            if "issue_frac" in pf and "lane_util" in pf:
+                # the EXECUTED-work figure: share of the chip's VALU lane-cycles that did something
+                pf["lane_cycle_frac"] = round(pf["issue_frac"] * pf["lane_util"], 4)
+        rl["profiled"] = pf
+        rl["frac_note"] = ("frac prices the REFERENCE algorithm's operation count (both children, unshrunk interval) at "
+                           "this launch time; the executed share of VALU lane-cycles is profiled.lane_cycle_frac")
     rl["algorithmic_bytes"] = {
         "bytes_per_sample": round(work["bytes"], 2), "gb_per_s": round(algo_gbs, 3),
         "over_hbm_peak": round(algo_gbs / roofline.HBM_PEAK_GBS, 4),
@@ -412,13 +568,13 @@ def main():
                       "operation counters, gcc -O3 -march=native on this host)"
                       % (args.cpu_rows, nx, args.cpu_spp, args.scene, nx, ny, dt_cpu),
             "gpu_over_cpu": round(value / cpu_ms, 1),
+            "host_cores": host_cores,
+            "usable_cores": usable_cores,
             "all_cores": allcore,
         }
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -122,14 +122,14 @@ class Scene:
         self.uploaded = True
         return self
 
-    def render(self, cam, nx, ny, ns, sig=False, **kw):
-        """Blocking whole-image render -> dict(linear f32 [ny,nx,3], rgb8 u8 [ny,nx,3], stats[, sig u64 [ny,nx]])."""
+    def render(self, cam, nx, ny, ns, sig=False, out=None, **kw):
+        """Blocking whole-image render -> dict(linear f32 [ny,nx,3], rgb8 u8 [ny,nx,3], stats[, sig u64 [ny,nx]]).
+        `out` = (linear, rgb8) arrays to reuse."""
         if not self.uploaded:
             self.upload(kw.pop("device", 0))
         kw.pop("device", None)
         p = default_params(nx, ny, ns, **kw)
-        lin = np.zeros((ny, nx, 3), np.float32)
-        rgb = np.zeros((ny, nx, 3), np.uint8)
+        lin, rgb = out if out is not None else (np.zeros((ny, nx, 3), np.float32), np.zeros((ny, nx, 3), np.uint8))
         sg = np.zeros((ny, nx), np.uint64) if sig else None
         st = abi.Stats()
         self.host._check(self.host.lib.rth_render(self.h, cam.h, C.byref(p), lin.ctypes.data, rgb.ctypes.data,

@@ -25,28 +25,28 @@ __global__ void k(unsigned long long *out, int iters) {
         if (MODE == 0) {
             REP16(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n"
                                "s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n"
-                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7));)
+                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : : "scc", "vcc");)
         } else if (MODE == 1) {
             REP16(asm volatile("v_add_f32 %0, %0, 1.0\n v_add_f32 %1, %1, 1.0\n v_add_f32 %2, %2, 1.0\n v_add_f32 %3, %3, 1.0\n"
                                "v_add_f32 %4, %4, 1.0\n v_add_f32 %5, %5, 1.0\n v_add_f32 %6, %6, 1.0\n v_add_f32 %7, %7, 1.0\n"
-                               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7));)
+                               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : : "scc", "vcc");)
         } else if (MODE == 2) {
             REP16(asm volatile("s_add_u32 %0, %0, 1\n v_add_f32 %4, %4, 1.0\n s_add_u32 %1, %1, 1\n v_add_f32 %5, %5, 1.0\n"
                                "s_add_u32 %2, %2, 1\n v_add_f32 %6, %6, 1.0\n s_add_u32 %3, %3, 1\n v_add_f32 %7, %7, 1.0\n"
-                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : : "scc", "vcc");)
         } else if (MODE == 3) {
             REP16(asm volatile("s_and_b64 %0, %0, %1\n s_or_b64 %1, %1, %2\n s_and_b64 %2, %2, %3\n s_or_b64 %3, %3, %0\n"
                                "s_and_b64 %0, %0, %2\n s_or_b64 %1, %1, %3\n s_and_b64 %2, %2, %0\n s_or_b64 %3, %3, %1\n"
-                               : "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3));)
+                               : "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3) : : "scc", "vcc");)
         } else if (MODE == 4) {
             REP16(asm volatile("s_add_u32 %0, %0, 1\n v_add_f32 %4, %4, 1.0\n s_add_u32 %1, %1, 1\n v_add_f32 %5, %5, 1.0\n"
                                "s_add_u32 %2, %2, 1\n v_add_f32 %6, %6, 1.0\n s_cmp_eq_u32 %3, 0\n v_add_f32 %7, %7, 1.0\n"
                                "s_cbranch_scc1 1f\n s_nop 0\n1:\n"
-                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));)
+                               : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : : "scc", "vcc");)
         } else {
             REP16(asm volatile("v_cmp_gt_f32_e64 %4, %0, %1\n v_cmp_lt_f32_e64 %5, %2, %3\n s_and_b64 %4, %4, %5\n v_cndmask_b32_e64 %0, %0, %1, %4\n"
                                "v_cmp_gt_f32_e64 %6, %2, %3\n v_cmp_lt_f32_e64 %7, %0, %1\n s_and_b64 %6, %6, %7\n v_cndmask_b32_e64 %2, %2, %3, %6\n"
-                               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3));)
+                               : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3) : : "scc", "vcc");)
         }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -83,6 +83,7 @@ static void run(const char *name, int per_iter, unsigned long long *d, int cus) 
 }
 
 int main() {
+    setvbuf(stdout, NULL, _IONBF, 0);
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
