@@ -202,10 +202,7 @@ typedef struct {
 #define RTMI_FLAG_REF_TREE 64u /* cooperative kernel: walk the reference-topology tree, not the alternative one */
 /* Diagnostic knobs in the upper flag bits (results never depend on them): bits 8..10 = wavefronts per SIMD the
  * cooperative kernel is compiled for (3 or 5; default 4); bit 11 = a 256-entry LDS part of the traversal stack,
- * so that it spills to global memory all the time (tests/test_gpu_parity.py); bits 16..22 = the cooperative kernel's
- * "third station": when the last item of the world list is a BVH (and not the only item), lanes whose ray passes its
- * root box wait until this many of them do before its traversal runs (0 = default 32, 1..64, 127 = off). */
-#define RTMI_FLAG_PARK_SHIFT 16
+ * so that it spills to global memory all the time (tests/test_gpu_parity.py). */
 #define RTMI_FLAG_SKY 32u      /* opt-in extension, off by default: a ray that misses the world returns the gradient
                                 * the reference keeps commented out at src/color.rs:18-20 instead of black (:21) */
 /* Two more opt-in extensions, off by default; the default path reproduces the reference's quirks. */

@@ -12,17 +12,15 @@ __device__ __forceinline__ bool aabb_hit_t(float mnx, float mny, float mnz, floa
     bool neg = r.inv_d.x < 0.0f;
     t_min = fmaxf(t_min, neg ? t1 : t0);
     t_max = fminf(t_max, neg ? t0 : t1);
-    bool fail = t_max <= t_min;
     t0 = (mny - r.o.y) * r.inv_d.y; t1 = (mxy - r.o.y) * r.inv_d.y;
     neg = r.inv_d.y < 0.0f;
     t_min = fmaxf(t_min, neg ? t1 : t0);
     t_max = fminf(t_max, neg ? t0 : t1);
-    fail |= t_max <= t_min;
     t0 = (mnz - r.o.z) * r.inv_d.z; t1 = (mxz - r.o.z) * r.inv_d.z;
     neg = r.inv_d.z < 0.0f;
     t_min = fmaxf(t_min, neg ? t1 : t0);
     t_max = fminf(t_max, neg ? t0 : t1);
-    fail |= t_max <= t_min;
+    const bool fail = t_max <= t_min; // one comparison after the last axis: see aabb_hit (rtmi_geom.hpp)
     t_enter = t_min;
     return !fail;
 }

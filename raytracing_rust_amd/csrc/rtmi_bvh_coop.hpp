@@ -24,6 +24,7 @@
 // the pool by 64 * (tree depth + 1) entries; the caller reports an overflow loudly.
 // ----------------------------------------------------------------------------------
 #define COOP_NONE 0xffffffffu
+#define RTMI_COOP_DUMMY_WORDS 128u /* one uint2 per lane behind `best`: target of the stores of children that are not published */
 #define COOP_SENTINEL 0xffffffffffffffffull
 __device__ __forceinline__ uint32_t f2sort(float f) {
     const uint32_t u = __float_as_uint(f);
@@ -36,7 +37,7 @@ __device__ __forceinline__ float sort2f(uint32_t s) {
 // (< 2^25); a leaf is 1<<25 | type<<22 | primitive (< 2^22).  rtmi_scene_create stores both children of every
 // node in this encoding in the node record's reserved words.
 
-// Work space of one wavefront.  LDS (uint32 words): pool [cap][2] | ctx [64][12] floats | best [64] uint64.
+// Work space of one wavefront.  LDS (uint32 words): pool [cap][2] | ctx [64][12] floats | best [64] uint64 | dummy [64][2].
 // The pool in LDS is the TOP of the logical LIFO; when it runs full its older half moves to `spill` (global
 // memory, private to the wavefront) and comes back when the LDS part is empty, so the logical stack and
 // its depth-first bound of 64 * (tree depth + 1) entries are unchanged while the LDS footprint does not
@@ -139,7 +140,9 @@ __device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bo
             // test, and an empty slot's reference must never reach the pool)
             const bool okc = !(tn > tf) && wch[c] != COOP_NONE;
             if (okc) wkeep |= 1u << c;
-            if (okc && tn < tnear) { nearest = c; tnear = tn; }
+            // (!(tn >= tnear), not tn < tnear: with a NaN entry distance — a NaN q_min — some surviving child still
+            // becomes the nearest, so at most three are ever left to publish)
+            if (okc && !(tn >= tnear)) { nearest = c; tnear = tn; }
         }
         if (nearest >= 0) { cur = wch[nearest]; tent = tnear; wkeep &= ~(1u << nearest); } else cur = COOP_NONE;
         npush = __popc(wkeep); // what is left gets published
@@ -151,10 +154,14 @@ __device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bo
         const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
                            2 * (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
         int at = top + before;
+        // Unconditional stores: a child that is not published goes to the worker's own dummy entry behind `best` — a
+        // v_cndmask on the address instead of an exec-mask region (three scalar instructions) per child.
+        const int dummy = cap + 64 * 6 + 64 + lane; // in uint2 units from `pool`: behind ctx (64 x 48 B) and best (64 x 8 B)
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            if (wkeep & (1u << c)) pool[at] = make_uint2(((uint32_t)ray << 26) | wch[c], __float_as_uint(wtn[c]));
-            at += (int)((wkeep >> c) & 1u);
+            const bool on = (wkeep & (1u << c)) != 0u;
+            pool[on ? at : dummy] = make_uint2(((uint32_t)ray << 26) | wch[c], __float_as_uint(wtn[c]));
+            at += on ? 1 : 0;
         }
         top += __popcll(b0) + 2 * __popcll(b1);
     };
@@ -173,9 +180,9 @@ __device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bo
             break;
         }
         const int take = n_need < top ? n_need : top;
-        if (needw) {
+        {
             const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
-            if (r < take) {
+            if (needw && r < take) { // one exec-mask region (scalar instructions are the dear ones here: rtmi_geom.hpp)
                 const int idx = top - 1 - r;
                 const uint2 e = pool[idx];
                 tent = __uint_as_float(e.y);
@@ -190,8 +197,8 @@ __device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bo
         float push_t = 0.0f;
         int npush = 0;                    // W4: up to three of the four children are published
         uint32_t wkeep = 0u;              // bit c: child c is published (wch / wtn: declared outside the loop)
-        if (cur != COOP_NONE) {
-            if (ray != cray) { // switch ray context
+        {
+            if (cur != COOP_NONE && ray != cray) { // switch ray context
                 const float4 c0 = ctx[ray * 3 + 0], c1 = ctx[ray * 3 + 1], c2 = ctx[ray * 3 + 2];
                 W.o = f3(c0.x, c0.y, c0.z); wtime = c0.w;
                 W.d = f3(c1.x, c1.y, c1.z); wqmin = c1.w;
@@ -202,18 +209,16 @@ __device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bo
                         fminf(fminf(__builtin_fabsf(W.inv_d.x), __builtin_fabsf(W.inv_d.y)), __builtin_fabsf(W.inv_d.z));
                 cray = ray;
             }
-            // the ray's best hit so far -> pruning limit
+            // the ray's best hit so far -> pruning limit (idle workers read the slot of the ray they held last: harmless)
             const unsigned long long key = best[ray];
-            float limit = RTMI_FLT_MAX;
-            if (key != COOP_SENTINEL) {
-                const float bt = sort2f((uint32_t)(key >> 32));
-                limit = bt + (__builtin_fabsf(bt) * (1.0f / 128.0f) + wmabs);
-            }
-            if (tent > limit) {
-                cur = COOP_NONE;
-            } else if (W4 && !(cur & (1u << 25))) { // internal node of the 4-wide tree
+            // select form (no exec-mask region): the sentinel decodes to a NaN pattern whose "limit" is discarded
+            const float bt = sort2f((uint32_t)(key >> 32));
+            const float lim = bt + (__builtin_fabsf(bt) * (1.0f / 128.0f) + wmabs);
+            const float limit = key != COOP_SENTINEL ? lim : RTMI_FLT_MAX;
+            if (tent > limit) cur = COOP_NONE; // (an idle worker's cur is COOP_NONE already: all its bits are set)
+            if (W4 && !(cur & (1u << 25))) { // internal node of the 4-wide tree
                 visit4(limit, wkeep, npush);
-            } else if (!(cur & (1u << 25))) { // internal node
+            } else if (!W4 && !(cur & (1u << 25))) { // internal node
                 const float4 *n = sc.nodes + (size_t)cur * 4;
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
                 // child references in pool encoding (filled in by rtmi_scene_create from left/right = n3.x, n3.y)

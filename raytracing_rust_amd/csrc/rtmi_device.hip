@@ -34,10 +34,6 @@
 
 #include "rtmi_kernels.hpp"
 
-#ifndef RTMI_PARK_DEFAULT
-#define RTMI_PARK_DEFAULT 32u
-#endif
-
 // ======================================================================================
 // host side of the C ABI
 // ======================================================================================
@@ -58,7 +54,6 @@ struct rtmi_scene {
     DevScene dev{};
     std::vector<void *> allocs;
     rtmi_scene_desc meta{}; // counts only (pointers nulled)
-    rtmi_item last_item{};  // host copy of the last item of the world list (scheduling decision of the cooperative kernel)
     double *partial = nullptr; // f64 radiance sums [local tile][3][64], carried between passes
     size_t partial_bytes = 0;
     float4 *samples = nullptr; // per-sample radiance [local tile][pass samples][64]
@@ -339,7 +334,6 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     for (uint32_t i = 0; i < d->n_items; i++)
         if (d->items[i].kind == RTMI_ITEM_BVH && d->items[i].alt_first >= 0) s->has_alt = true;
     s->dev.n_items = d->n_items;
-    s->last_item = d->items[d->n_items - 1u];
     if (hipMalloc(reinterpret_cast<void **>(&s->status), RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess ||
         hipMemset(s->status, 0, RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess) {
         rtmi_scene_destroy(s);
@@ -550,13 +544,6 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     // LDS part of the traversal stack: 512 entries cover the deepest stack ever seen on the reference scenes
     // (447); deeper stacks continue in global memory (64 * (depth + 2) entries per wavefront, the bound of the
     // depth-first order), so the LDS footprint (7.7 KB per wavefront) does not depend on the tree depth
-    {   // third station (rtmi_kernels.hpp): the last item of the world list is a plain (non-medium) BVH and not the
-        // only item.  Diagnostic knob in flag bits 16..22: 0 = default, 1..64 = lanes to wait for, 127 = off.
-        const rtmi_item &li = s->last_item;
-        const uint32_t knob = (p->flags >> 16) & 0x7fu;
-        const bool eligible = s->meta.n_items > 1u && li.kind == RTMI_ITEM_BVH && !(li.flags & RTMI_ITEMFLAG_MEDIUM);
-        P.park_threshold = (!eligible || knob == 127u) ? 0u : (knob ? (knob > 64u ? 64u : knob) : RTMI_PARK_DEFAULT);
-    }
     P.use_alt = (s->dev.gate != nullptr && s->has_alt && !(p->flags & RTMI_FLAG_REF_TREE)) ? 1u : 0u;
     const uint32_t deepest = (P.use_alt && s->meta.alt_max_depth > s->meta.max_bvh_depth) ? s->meta.alt_max_depth : s->meta.max_bvh_depth;
     P.spill_cap = 64u * (deepest + 2u);
@@ -587,7 +574,7 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
         }
     }
     P.spill = s->spill;
-    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u + (ext ? 0u : RTMI_RNG_RING_WORDS)) * sizeof(uint32_t);
+    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + (ext ? 0u : RTMI_RNG_RING_WORDS)) * sizeof(uint32_t);
     const uint32_t ntex = P.ntiles_local * 64u;
     uint32_t blocks_total = 0, chunks_total = 0;
     for (uint32_t s0 = 0; s0 < p->ns; s0 += pass_ns) { // one pass unless the sample buffer is smaller than ns samples

@@ -73,6 +73,24 @@ __device__ __forceinline__ void ray_derive(RayF &r) {
 // AABB::hit — src/aabb.rs:31-44.  The sequential early-out is an OR of the three tests.
 __device__ __forceinline__ bool aabb_hit(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                                          const RayF &r, float t_min, float t_max) {
+#ifndef RTMI_BRANCHY_TESTS
+    // aabb.rs:41-43 returns false as soon as t_max <= t_min after an axis.  t_min never decreases and t_max never
+    // increases from axis to axis (fmaxf / fminf, which also ignore a NaN slab distance exactly like f64::max / min),
+    // so "after some axis" <=> "after the last axis": one comparison instead of three and their two mask ORs.
+    float t0 = (mnx - r.o.x) * r.inv_d.x, t1 = (mxx - r.o.x) * r.inv_d.x;
+    bool neg = r.inv_d.x < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    t0 = (mny - r.o.y) * r.inv_d.y; t1 = (mxy - r.o.y) * r.inv_d.y;
+    neg = r.inv_d.y < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    t0 = (mnz - r.o.z) * r.inv_d.z; t1 = (mxz - r.o.z) * r.inv_d.z;
+    neg = r.inv_d.z < 0.0f;
+    t_min = fmaxf(t_min, neg ? t1 : t0);
+    t_max = fminf(t_max, neg ? t0 : t1);
+    return !(t_max <= t_min);
+#else
     float t0 = (mnx - r.o.x) * r.inv_d.x, t1 = (mxx - r.o.x) * r.inv_d.x;
     bool neg = r.inv_d.x < 0.0f;
     t_min = fmaxf(t_min, neg ? t1 : t0);
@@ -89,6 +107,7 @@ __device__ __forceinline__ bool aabb_hit(float mnx, float mny, float mnz, float 
     t_max = fminf(t_max, neg ? t0 : t1);
     fail |= t_max <= t_min;
     return !fail;
+#endif
 }
 
 // Sphere::hit / MovingSphere::hit — src/sphere.rs:37-77, 122-164 (t only; the record is
@@ -98,6 +117,18 @@ __device__ __forceinline__ bool sphere_test(const RayF &r, F3 c, float radius, f
     float b = dot(oc, r.d);
     float cc = dot(oc, oc) - radius * radius;
     float disc = b * b - r.a * cc;
+#ifndef RTMI_BRANCHY_TESTS
+    // select form (r03): both roots are evaluated and the first one inside (t_min, t_max) is kept, as sphere.rs:44-74
+    // does with two early returns; the same comparisons on the same values (sqrt of a non-positive discriminant gives
+    // NaN or 0 and is masked by disc > 0), without the three nested exec-mask regions
+    const float sq = __builtin_sqrtf(disc);
+    const float t1 = (-b - sq) * r.inv_a, t2 = (-b + sq) * r.inv_a;
+    const bool pos = disc > 0.0f;
+    const bool ok1 = pos & (t1 < t_max) & (t1 > t_min);
+    const bool ok2 = pos & (t2 < t_max) & (t2 > t_min);
+    t_out = ok1 ? t1 : (ok2 ? t2 : t_out);
+    return ok1 | ok2;
+#else
     if (disc > 0.0f) {
         float sq = __builtin_sqrtf(disc);
         float t = (-b - sq) * r.inv_a;
@@ -106,6 +137,7 @@ __device__ __forceinline__ bool sphere_test(const RayF &r, F3 c, float radius, f
         if (t < t_max && t > t_min) { t_out = t; return true; }
     }
     return false;
+#endif
 }
 // ConstantMedium::hit's two boundary queries (medium.rs:29-30) against ONE static sphere:
 //   boundary.hit(ray, -MAX, MAX) -> t1, then boundary.hit(ray, t1 + 0.0001, MAX) -> t2.
@@ -135,6 +167,13 @@ __device__ __forceinline__ F3 moving_center(float4 A, float4 B, float inv_dt, fl
 }
 
 // Rect::hit — src/rect.rs:39-69 with (k,a,b) = YZ:(0,1,2) ZX:(1,2,0) XY:(2,0,1)
+// Branch-free form (r03).  The reference rejects iff  t < t_min || t > t_max || x < x0 || x > x1 || y < y0 || y > y1.
+// In IEEE arithmetic with denormals kept  a < b  <=>  b - a > 0  exactly (a difference is zero only for equal operands,
+// its sign is never lost), and a NaN operand makes the comparison false just as fmaxf ignores a NaN difference; so the
+// same decision is  max(t_min - t, t - t_max, x0 - x, x - x1, y0 - y, y - y1) > 0  (all NaN: not rejected, like the six
+// false comparisons).  Six subtractions and three v_max3 replace six compares, their five scalar mask combinations and
+// the two divergent early-outs: on gfx950 a scalar instruction occupies its issue port for 4 cycles, shared by the
+// wavefronts of a SIMD, a vector instruction for 2 (tools/micro/issue_share.hip) — the scalar side is what binds here.
 template <int P>
 __device__ __forceinline__ bool rect_test(float x0, float y0, float x1, float y1, float k, const RayF &r, float t_min,
                                           float t_max, float &t_out) {
@@ -142,12 +181,21 @@ __device__ __forceinline__ bool rect_test(float x0, float y0, float x1, float y1
     constexpr int A = P == 0 ? 1 : (P == 1 ? 2 : 0);
     constexpr int B = P == 0 ? 2 : (P == 1 ? 0 : 1);
     float t = (k - comp<K>(r.o)) * comp<K>(r.inv_d);
+#ifndef RTMI_BRANCHY_TESTS
+    const float x = comp<A>(r.o) + t * comp<A>(r.d);
+    const float y = comp<B>(r.o) + t * comp<B>(r.d);
+    const float m = fmaxf(fmaxf(fmaxf(t_min - t, t - t_max), fmaxf(x0 - x, x - x1)), fmaxf(y0 - y, y - y1));
+    if (m > 0.0f) return false;
+    t_out = t;
+    return true;
+#else
     if (t < t_min || t > t_max) return false;
     float x = comp<A>(r.o) + t * comp<A>(r.d);
     float y = comp<B>(r.o) + t * comp<B>(r.d);
     if (x < x0 || x > x1 || y < y0 || y > y1) return false;
     t_out = t;
     return true;
+#endif
 }
 __device__ __forceinline__ bool rect_test_rt(int plane, float4 A, float k, const RayF &r, float t_min, float t_max,
                                              float &t_out) {
@@ -160,7 +208,22 @@ __device__ __forceinline__ bool rect_test_rt(int plane, float4 A, float k, const
 __device__ __forceinline__ bool cube_test(float4 A, float4 B, const RayF &r, float t_min, float t_max, float &t_out,
                                           int &face) {
     const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
-    float cl = t_max, t;
+    float cl = t_max, t = 0.0f;
+#ifndef RTMI_BRANCHY_TESTS
+    // select form: every face is evaluated, the closest so far and its face number move by v_cndmask (no exec-mask
+    // regions); the scan order and the shrinking interval are those of the list scan, so ties resolve the same way
+    int f = -1;
+    bool h;
+    h = rect_test<2>(ax, ay, bx, by, bz, r, t_min, cl, t); cl = h ? t : cl; f = h ? 0 : f;
+    h = rect_test<2>(ax, ay, bx, by, az, r, t_min, cl, t); cl = h ? t : cl; f = h ? 1 : f;
+    h = rect_test<1>(az, ax, bz, bx, by, r, t_min, cl, t); cl = h ? t : cl; f = h ? 2 : f;
+    h = rect_test<1>(az, ax, bz, bx, ay, r, t_min, cl, t); cl = h ? t : cl; f = h ? 3 : f;
+    h = rect_test<0>(ay, az, by, bz, bx, r, t_min, cl, t); cl = h ? t : cl; f = h ? 4 : f;
+    h = rect_test<0>(ay, az, by, bz, ax, r, t_min, cl, t); cl = h ? t : cl; f = h ? 5 : f;
+    t_out = cl;
+    face = f < 0 ? 0 : f;
+    return f >= 0;
+#else
     bool any = false;
     if (rect_test<2>(ax, ay, bx, by, bz, r, t_min, cl, t)) { cl = t; any = true; face = 0; }
     if (rect_test<2>(ax, ay, bx, by, az, r, t_min, cl, t)) { cl = t; any = true; face = 1; }
@@ -170,6 +233,7 @@ __device__ __forceinline__ bool cube_test(float4 A, float4 B, const RayF &r, flo
     if (rect_test<0>(ay, az, by, bz, ax, r, t_min, cl, t)) { cl = t; any = true; face = 5; }
     t_out = cl;
     return any;
+#endif
 }
 
 // one primitive against (t_min, t_max); pf = prim << 3 | face.  The three planes are loaded up
@@ -199,10 +263,12 @@ __device__ __forceinline__ bool prim_test_vals(int type, int idx, float4 A, floa
                                                float time, float t_min, float t_max, float &t_out, int &pf) {
     bool h = false;
     int face = 0;
-    if (type == RTMI_PRIM_SPHERE) {
-        h = sphere_test(r, f3(A.x, A.y, A.z), A.w, t_min, t_max, t_out);
-    } else if (type == RTMI_PRIM_MSPHERE) {
-        h = sphere_test(r, moving_center(A, B, m_inv_dt, time), A.w, t_min, t_max, t_out);
+    if (type <= RTMI_PRIM_MSPHERE) {
+        // one sphere test for both kinds (one exec-mask region less, one copy of the test): the centre is selected,
+        // not blended — a static sphere's centre is plane A as stored
+        const F3 cm = moving_center(A, B, m_inv_dt, time);
+        const bool mv = type == RTMI_PRIM_MSPHERE;
+        h = sphere_test(r, f3(mv ? cm.x : A.x, mv ? cm.y : A.y, mv ? cm.z : A.z), A.w, t_min, t_max, t_out);
     } else if (type == RTMI_PRIM_RECT) {
         const int plane = (int)((m_flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
         h = rect_test_rt(plane, A, B.x, r, t_min, t_max, t_out);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     const int wave = threadIdx.x >> 6;
     CoopWork cw;
     cw.cap = (int)P.coop_cap;
-    cw.wlds = lds_dyn + (size_t)wave * (2u * cw.cap + 64u * 12u + 128u + (EXT ? 0u : RTMI_RNG_RING_WORDS));
+    cw.wlds = lds_dyn + (size_t)wave * (2u * cw.cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + (EXT ? 0u : RTMI_RNG_RING_WORDS));
     cw.spill_cap = (int)P.spill_cap;
     cw.spill = P.spill + (size_t)(blockIdx.x * WAVES_PER_BLOCK + wave) * P.spill_cap;
     unsigned long long sig = 0ull;
@@ -164,19 +164,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
 
     uint32_t oidx = 0u, ltile = 0u; // slot of this lane's path in the per-sample buffer; its local tile (SIG only)
     bool alive = false, done = false, have_hit = false, overflow = false;
-    // Third station of the schedule (r03; P.park_threshold != 0 only when the LAST item of the world list is a BVH and
-    // not the only item): a lane whose ray has been through every other item and passes that BVH's root box is PARKED
-    // with its closest hit so far, and the cooperative traversal of the item runs for all parked lanes together once
-    // park_threshold of them wait (or nothing else in the wavefront can make progress) — exactly as lanes holding a
-    // hit wait for phase B.  final_scene: only a third of the rays pass the root box of the 1000-sphere BVH, so its
-    // traversal ran with 28 % of the workers busy.  Per-lane program order (items in list order, hittable.rs:37-47)
-    // is unchanged: the deferred item is the last one, so nothing of the same query comes after it.
-    const uint32_t last_item = sc.n_items - 1u;
-    const int park_n = (int)P.park_threshold;
-    bool parked = false;
     // lean instantiation (scenes without alternative trees): word ring in LDS behind pool | ctx | best
     typename std::conditional<EXT, RngReg, RngRing>::type g;
-    rng_attach(g, cw.wlds + 2u * cw.cap + 64u * 12u + 128u);
+    rng_attach(g, cw.wlds + 2u * cw.cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS);
     rng_init(g, 0, 0);
     Path pa;
     pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
@@ -202,14 +192,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     }
                 }
             }
-            const bool need = !have_hit && !done && !parked;
+            const bool need = !have_hit && !done;
             prof_tick<PROF>(prof, 0, need);
             prof_time<PROF>(prof, 25, tstamp); // camera samples
             RayF W;
-            W.o = pa.ro; W.d = pa.rd; // (a parked lane's path has not moved: the same ray as when it was parked)
+            W.o = pa.ro; W.d = pa.rd;
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
-            bool finish = need; // lanes whose world.hit() is complete at the end of this iteration
             for (uint32_t it = 0; it < sc.n_items; it++) { // executed by all 64 lanes
                 const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, sc.items + it);
                 RayF R = W;
@@ -220,21 +209,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                     float t;
                     int pf;
-                    bool act = need;
-                    if (park_n != 0 && it == last_item) { // wave-uniform
-                        const bool enter = need && aabb_hit(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0], I.root_max[1],
-                                                            I.root_max[2], R, P.t_min, closest); // bvh.rs:71
-                        parked = parked || enter;
-                        finish = need && !enter;
-                        // run the deferred traversal now?  Enough lanes wait — or nothing else can happen in this
-                        // wavefront: no lane is about to start a new path and too few hold a hit for phase B
-                        const int n_hit = __popcll(__ballot(have_hit || (finish && best_item >= 0)));
-                        const bool flush = __popcll(__ballot(parked)) >= park_n ||
-                                           (__ballot(finish && best_item < 0) == 0ull && n_hit < threshold);
-                        act = flush && parked;
-                        if (flush) { finish = finish || parked; parked = false; }
-                    }
-                    if (geom_query_coop<PROF, EXT, EXT>(sc, I, P.use_alt != 0u, act, R, pa.rtime, P.t_min, closest, cw, t, pf, overflow, prof, slot)) {
+                    if (geom_query_coop<PROF, EXT, EXT>(sc, I, P.use_alt != 0u, need, R, pa.rtime, P.t_min, closest, cw, t, pf, overflow, prof, slot)) {
                         closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                     }
                     prof_time<PROF>(prof, I.kind == RTMI_ITEM_BVH ? (it == 0 ? 27 : 28) : 26, tstamp);
@@ -261,7 +236,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     prof_time<PROF>(prof, 29, tstamp); // media
                 }
             }
-            if (finish) {
+            if (need) {
                 if (best_item >= 0) {
                     have_hit = true;
                 } else { // miss: black background (color.rs:21)

@@ -84,7 +84,6 @@ struct DevParams {
     uint32_t sky; // RTMI_FLAG_SKY
     uint32_t use_alt; // cooperative kernel: walk the items' alternative trees, leaves accepted through their gate
     uint32_t ext;     // opt-in extensions / test knobs: RTMI_EXT_*
-    uint32_t park_threshold; // cooperative kernel: lanes parked at the last (BVH) item before its traversal runs; 0 = off
 };
 // device-only item flag (set by rtmi_scene_create, never part of the ABI): MEDIUM item whose boundary is one static
 // sphere; root_min = its centre, root_max[0] = its radius
