@@ -30,8 +30,14 @@ fn zero_item() -> RtmiItem {
 fn leaf_ref(ty: i32, prim: usize) -> i32 {
     (0x8000_0000u32 | ((ty as u32) << 28) | prim as u32) as i32 // RTMI_LEAF(type, prim)
 }
+/// f64 -> f32, one rounding; beyond the f32 range (Rotate::bounding_box is the whole f64 space, rotate.rs:36-37)
+/// saturating at +-FLT_MAX, like rt_host.cpp sat_f32
+fn sat_f32(v: f64) -> f32 {
+    let big = F32_MAX as f64;
+    if v > big { F32_MAX } else if v < -big { -F32_MAX } else { v as f32 }
+}
 fn put_box(b: &Aabb) -> ([f32; 3], [f32; 3]) {
-    ([b.min[0] as f32, b.min[1] as f32, b.min[2] as f32], [b.max[0] as f32, b.max[1] as f32, b.max[2] as f32])
+    ([sat_f32(b.min[0]), sat_f32(b.min[1]), sat_f32(b.min[2])], [sat_f32(b.max[0]), sat_f32(b.max[1]), sat_f32(b.max[2])])
 }
 fn pad_box(b: &Aabb, pad: f64) -> Aabb {
     Aabb { min: [b.min[0] - pad, b.min[1] - pad, b.min[2] - pad], max: [b.max[0] + pad, b.max[1] + pad, b.max[2] + pad] }
@@ -45,9 +51,50 @@ fn strip_flips<'a>(mut h: &'a Rc<HittableDesc>, flip: &mut bool) -> &'a Rc<Hitta
     }
     h
 }
+/// Strips the wrappers a device PRIMITIVE may carry — FlipNormals, Traslate, Rotate, in any order and number — and
+/// returns the innermost object; `chain` receives the transforms outermost first (rt_host.cpp strip_wrappers).
+fn strip_wrappers<'a>(mut h: &'a Rc<HittableDesc>, flip: &mut bool, mut chain: Option<&mut Vec<RtmiXform>>) -> &'a Rc<HittableDesc> {
+    loop {
+        match &**h {
+            HittableDesc::FlipNormals { inner } => {
+                *flip = !*flip;
+                h = inner;
+            }
+            HittableDesc::Traslate { inner, offset } => {
+                if let Some(c) = chain.as_mut() {
+                    c.push(RtmiXform { kind: RTMI_XF_TRANSLATE, x: offset[0] as f32, y: offset[1] as f32, z: offset[2] as f32 });
+                }
+                h = inner;
+            }
+            HittableDesc::Rotate { axis, inner, sin_theta, cos_theta } => {
+                if let Some(c) = chain.as_mut() {
+                    c.push(RtmiXform { kind: RTMI_XF_ROTATE_X + *axis as i32, x: *sin_theta as f32, y: *cos_theta as f32, z: 0.0 });
+                }
+                h = inner;
+            }
+            _ => return h,
+        }
+    }
+}
+/// object -> world through a chain (outermost first), in f64 with the f32 sines / cosines the device uses: innermost
+/// wrapper first (traslate.rs:21-22, rotate.rs:94-105) — rt_host.cpp chain_to_world
+fn chain_to_world(chain: &[RtmiXform], mut p: [f64; 3]) -> [f64; 3] {
+    for x in chain.iter().rev() {
+        if x.kind == RTMI_XF_TRANSLATE {
+            p = [p[0] + x.x as f64, p[1] + x.y as f64, p[2] + x.z as f64];
+            continue;
+        }
+        let r = (x.kind - RTMI_XF_ROTATE_X) as usize;
+        let (a, b) = ((r + 1) % 3, (r + 2) % 3);
+        let (s, c, pa, pb) = (x.x as f64, x.y as f64, p[a], p[b]);
+        p[a] = c * pa - s * pb;
+        p[b] = s * pa + c * pb;
+    }
+    p
+}
 fn contains_moving(h: &Rc<HittableDesc>) -> bool {
     let mut dummy = false;
-    match &**strip_flips(h, &mut dummy) {
+    match &**strip_wrappers(h, &mut dummy, None) {
         HittableDesc::MovingSphere { .. } => true,
         HittableDesc::Bvh { left, right, .. } => contains_moving(left) || contains_moving(right),
         _ => false,
@@ -55,7 +102,7 @@ fn contains_moving(h: &Rc<HittableDesc>) -> bool {
 }
 fn moving_time_range(h: &Rc<HittableDesc>, lo: &mut f32, hi: &mut f32) {
     let mut dummy = false;
-    match &**strip_flips(h, &mut dummy) {
+    match &**strip_wrappers(h, &mut dummy, None) {
         HittableDesc::MovingSphere { time0, time1, .. } => {
             *lo = lo.max(time0.min(*time1) as f32);
             *hi = hi.min(time0.max(*time1) as f32);
@@ -71,7 +118,33 @@ fn moving_time_range(h: &Rc<HittableDesc>, lo: &mut f32, hi: &mut f32) {
 /// sphere over its own [time0, time1]; None = can never be hit (a rect with x0 > x1, rect.rs:51).
 fn true_bounds(h: &Rc<HittableDesc>) -> Option<Aabb> {
     let mut dummy = false;
-    match &**strip_flips(h, &mut dummy) {
+    let mut chain: Vec<RtmiXform> = Vec::new();
+    let inner = strip_wrappers(h, &mut dummy, Some(&mut chain));
+    let ib = true_bounds_inner(inner)?;
+    if chain.is_empty() {
+        return Some(ib);
+    }
+    // the box of the eight transformed corners, widened by a relative 1e-6 for the device's fp32 transforms
+    let mut out: Option<Aabb> = None;
+    for i in 0..8 {
+        let c = [if i & 1 != 0 { ib.max[0] } else { ib.min[0] }, if i & 2 != 0 { ib.max[1] } else { ib.min[1] }, if i & 4 != 0 { ib.max[2] } else { ib.min[2] }];
+        let w = chain_to_world(&chain, c);
+        let wb = Aabb { min: w, max: w };
+        out = Some(match out {
+            Some(o) => surrounding_box(&o, &wb),
+            None => wb,
+        });
+    }
+    let mut o = out.unwrap();
+    for k in 0..3 {
+        let e = 1e-6 * o.min[k].abs().max(o.max[k].abs());
+        o.min[k] -= e;
+        o.max[k] += e;
+    }
+    Some(o)
+}
+fn true_bounds_inner(h: &Rc<HittableDesc>) -> Option<Aabb> {
+    match &**h {
         HittableDesc::Rect { plane, x0, y0, x1, y1, k, .. } => {
             if x0 > x1 || y0 > y1 {
                 return None;
@@ -231,10 +304,25 @@ impl SceneBuilder {
     }
 
     /// one primitive -> planes A / B + meta (rt_host.cpp push_prim); returns its index
-    fn push_prim(&mut self, h: &HittableDesc, flip: bool, force_moving: bool) -> Result<usize, LowerError> {
+    fn push_prim(&mut self, h0: &Rc<HittableDesc>, flip: bool, force_moving: bool) -> Result<usize, LowerError> {
         let (mut a, mut b) = ([0.0f32; 4], [0.0f32; 4]);
+        // an instanced primitive: its own Traslate / Rotate chain (outermost first) goes to `xforms`, referenced from
+        // the meta word; FlipNormals anywhere in the chain only toggles the flag
+        let mut flip = flip;
+        let mut chain: Vec<RtmiXform> = Vec::new();
+        let h = strip_wrappers(h0, &mut flip, Some(&mut chain));
         let mut m = RtmiPrimMeta { material: 0, flags: if flip { RTMI_PRIMFLAG_FLIP } else { 0 }, inv_dt: 0.0, r#type: 0 };
-        match h {
+        if !chain.is_empty() {
+            if chain.len() > RTMI_PRIM_XF_MAX as usize {
+                return Err(LowerError::Unsupported("more than 15 Traslate/Rotate wrappers around one primitive".into()));
+            }
+            if self.out.xforms.len() + chain.len() >= (1usize << 20) {
+                return Err(LowerError::Unsupported("too many instance transforms".into()));
+            }
+            m.flags |= ((chain.len() as u32) << RTMI_PRIMFLAG_XF_COUNT_SHIFT) | ((self.out.xforms.len() as u32) << RTMI_PRIMFLAG_XF_FIRST_SHIFT);
+            self.out.xforms.extend_from_slice(&chain);
+        }
+        match &**h {
             HittableDesc::Sphere { center, radius, material } => {
                 a = [center[0] as f32, center[1] as f32, center[2] as f32, *radius as f32];
                 m.material = self.material_index(material);
@@ -328,7 +416,9 @@ impl SceneBuilder {
                 // spheres and for Rect.
                 let big = F32_MAX as f64;
                 let mut lb = Aabb { min: [-big; 3], max: [big; 3] };
-                let plain = !matches!(&**h, HittableDesc::MovingSphere { .. } | HittableDesc::Rect { .. });
+                let mut dummy2 = false;
+                let inner = strip_wrappers(h, &mut dummy2, None);
+                let plain = !matches!(&**inner, HittableDesc::MovingSphere { .. } | HittableDesc::Rect { .. });
                 if !unbounded_leaves && plain {
                     if let Some(t) = tb {
                         lb = pad_box(&t, pad);
@@ -574,7 +664,18 @@ impl SceneBuilder {
                     scale = scale.max(bbox.min[k].abs().max(bbox.max[k].abs()));
                 }
                 if !(scale < 1e30) {
-                    scale = 1e30;
+                    // a Rotate somewhere below makes every ancestor's box the whole space (rotate.rs:36-37): the margins
+                    // of the pruned traversal then scale with the geometry's TRUE extent
+                    let (_, tb) = contained(h, 1e300);
+                    scale = 0.0;
+                    if let Some(tb) = &tb {
+                        for k in 0..3 {
+                            scale = scale.max(tb.min[k].abs().max(tb.max[k].abs()));
+                        }
+                    }
+                    if tb.is_none() || !(scale < 1e30) {
+                        scale = 1e30;
+                    }
                 }
                 let (prunable, _) = contained(h, scale / 65536.0);
                 it.scale = if prunable { scale as f32 } else { 1e30 }; // 1e30: the pruning margin swallows every distance
@@ -605,7 +706,8 @@ impl SceneBuilder {
                     it.count += 1;
                 }
             }
-            prim => {
+            _prim => {
+                let prim = h;
                 // A run of consecutive plain primitives of the world list (no transform, no medium) becomes ONE list
                 // item: scanned in order with the shrinking t_max exactly as items are (hittable.rs:37-47).
                 if !medium && it.xform_count == 0 {

@@ -4,7 +4,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTMI_ABI_VERSION: u32 = 5;
+pub const RTMI_ABI_VERSION: u32 = 6;
 pub const RTMI_FLAG_FAST_CULL: u32 = 1;
 pub const RTMI_FLAG_PATH_SIG: u32 = 2;
 pub const RTMI_FLAG_PROFILE: u32 = 4;
@@ -39,6 +39,10 @@ pub const RTMI_PRIM_RECT: i32 = 2;
 pub const RTMI_PRIM_CUBE: i32 = 3;
 pub const RTMI_PRIMFLAG_FLIP: u32 = 1;
 pub const RTMI_PRIMFLAG_PLANE_SHIFT: u32 = 8;
+/// instanced primitive (rtmi.h): bits 4..7 = number of its own transforms, bits 12..31 = index of the first in xforms
+pub const RTMI_PRIMFLAG_XF_COUNT_SHIFT: u32 = 4;
+pub const RTMI_PRIMFLAG_XF_FIRST_SHIFT: u32 = 12;
+pub const RTMI_PRIM_XF_MAX: u32 = 15;
 pub const RTMI_XF_TRANSLATE: i32 = 0;
 pub const RTMI_XF_ROTATE_X: i32 = 1;
 pub const RTMI_XF_ROTATE_Y: i32 = 2;

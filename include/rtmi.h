@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 5u /* the scene description; entry points added since (rtmi_multi_*) do not change it */
+#define RTMI_ABI_VERSION 6u /* the scene description (6: instanced primitives, rtmi_prim_meta.flags bits 4..7, 12..31) */
 #define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
 #define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
 
@@ -91,6 +91,16 @@ typedef struct {
 enum { RTMI_PRIM_SPHERE = 0, RTMI_PRIM_MSPHERE = 1, RTMI_PRIM_RECT = 2, RTMI_PRIM_CUBE = 3 };
 #define RTMI_PRIMFLAG_FLIP 1u /* FlipNormals (hittable.rs:67-88) folded into the primitive */
 #define RTMI_PRIMFLAG_PLANE_SHIFT 8 /* RECT: Plane YZ=0, ZX=1, XY=2 (rect.rs:8-12) in bits 8..9 */
+/* Instanced primitive: Traslate<H> / Rotate<H> (src/traslate.rs:6-9, src/rotate.rs:21-28) are generic over any
+ * Hittable, so the reference lets them wrap a single primitive anywhere — as a member of a nested list or as a child of
+ * a BVHNode (bvh.rs:11-12).  Such a primitive carries its own transform chain: bits 4..7 = number of transforms
+ * (0 = none, at most RTMI_PRIM_XF_MAX), bits 12..31 = index of the first one in `xforms` (outermost wrapper first, like an
+ * item's chain).  The ray is taken into the primitive's frame before its test and the hit point / normal back after it
+ * (traslate.rs:18-24, rotate.rs:85-113), inside whatever frame the item's own chain has established.  In a BVH the node
+ * boxes above it are the reference's (Rotate::bounding_box is the whole space, rotate.rs:36-37). */
+#define RTMI_PRIMFLAG_XF_COUNT_SHIFT 4
+#define RTMI_PRIMFLAG_XF_FIRST_SHIFT 12
+#define RTMI_PRIM_XF_MAX 15u
 typedef struct {
     int32_t material;
     uint32_t flags;

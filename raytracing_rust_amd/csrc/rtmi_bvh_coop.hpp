@@ -60,7 +60,7 @@ struct CoopWork {
 #else
 #define RTMI_COOP_INLINE __forceinline__
 #endif
-template <bool PROF, bool EXT, bool W4>
+template <bool PROF, bool EXT, bool W4, bool INST>
 __device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bool gated, float scale, bool active, const RayF &R,
                                                float time, float q_min, float q_max, const CoopWork &cw,
                                                bool &have, float &t_out, int &pf_out, bool &overflow,
@@ -260,11 +260,11 @@ __device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bo
                 if (EXT && gated) { // one 80-B record: planes, meta and the gate box arrive together
                     const float4 *rec = sc.leaf_rec + (size_t)idx * 5;
                     const float4 A = rec[0], B = rec[1], M = rec[2], g0 = rec[3], g1 = rec[4];
-                    hit = prim_test_vals(type, idx, A, B, M.z, __float_as_uint(M.y), W, wtime, wqmin, wqmax, t, pf);
+                    hit = prim_test_vals<INST>(sc, type, idx, A, B, M.z, __float_as_uint(M.y), W, wtime, wqmin, wqmax, t, pf);
                     // alternative tree: the reference reaches this leaf iff its parent's box passes
                     if (hit) hit = aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, W, wqmin, wqmax);
                 } else {
-                    hit = prim_test(sc, type, idx, W, wtime, wqmin, wqmax, t, pf);
+                    hit = prim_test<INST>(sc, type, idx, W, wtime, wqmin, wqmax, t, pf);
                 }
                 if (hit) {
                     const unsigned long long k = ((unsigned long long)f2sort(t) << 32) | (unsigned long long)(0x7fffffffu - (uint32_t)pf);
@@ -328,7 +328,7 @@ __device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bo
 }
 
 // geometry of one item for the whole wavefront: every lane calls it; `active` lanes own a query
-template <bool PROF, bool EXT, bool W4>
+template <bool PROF, bool EXT, bool W4, bool INST>
 __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_item &I, bool use_alt, bool active, const RayF &r,
                                                 float time, float q_min, float q_max, const CoopWork &cw,
                                                 float &t_out, int &pf_out, bool &overflow, unsigned long long *prof,
@@ -339,8 +339,8 @@ __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_i
                                               I.root_max[2], r, q_min, q_max);
         bool have = false;
         const bool alt = EXT && W4 && use_alt && I.alt_first >= 0; // wave-uniform
-        if (alt) coop_bvh_query<PROF, EXT, W4>(sc, I.alt_first, true, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow, prof, slot);
-        else coop_bvh_query<PROF, EXT, false>(sc, I.first, false, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow, prof, slot);
+        if (alt) coop_bvh_query<PROF, EXT, W4, INST>(sc, I.alt_first, true, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow, prof, slot);
+        else coop_bvh_query<PROF, EXT, false, INST>(sc, I.first, false, I.scale, enter, r, time, q_min, q_max, cw, have, t_out, pf_out, overflow, prof, slot);
         return have;
     }
     // HittableList::hit — hittable.rs:37-47
@@ -352,7 +352,7 @@ __device__ __forceinline__ bool geom_query_coop(const DevScene &sc, const rtmi_i
             float t;
             int pf;
             prof_tick<PROF>(prof, 13, true);
-            if (prim_test_uniform(sc, idx, r, time, q_min, cl, t, pf)) { cl = t; any = true; pf_out = pf; }
+            if (prim_test_uniform<INST>(sc, idx, r, time, q_min, cl, t, pf)) { cl = t; any = true; pf_out = pf; }
         }
     }
     t_out = cl;

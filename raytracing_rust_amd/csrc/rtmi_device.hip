@@ -121,7 +121,11 @@ static int validate(const rtmi_scene_desc *d) {
         if (m.type < 0 || m.type > RTMI_PRIM_CUBE) return fail(RTMI_ERR_INVALID, "bad primitive type");
         if (m.material < 0 || (uint32_t)m.material >= d->n_materials)
             return fail(RTMI_ERR_INVALID, "primitive material out of range");
+        const uint32_t xfc = (m.flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX, xff = m.flags >> RTMI_PRIMFLAG_XF_FIRST_SHIFT;
+        if (xfc != 0u && ((uint64_t)xff + xfc > d->n_xforms)) return fail(RTMI_ERR_INVALID, "primitive transform range out of bounds");
     }
+    for (uint32_t i = 0; i < d->n_xforms; i++)
+        if (d->xforms[i].kind < RTMI_XF_TRANSLATE || d->xforms[i].kind > RTMI_XF_ROTATE_Z) return fail(RTMI_ERR_INVALID, "bad transform kind");
     for (uint32_t i = 0; i < d->n_nodes; i++) {
         const int32_t ch[2] = {d->nodes[i].left, d->nodes[i].right};
         for (int c = 0; c < 2; c++) {
@@ -334,6 +338,9 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     for (uint32_t i = 0; i < d->n_items; i++)
         if (d->items[i].kind == RTMI_ITEM_BVH && d->items[i].alt_first >= 0) s->has_alt = true;
     s->dev.n_items = d->n_items;
+    s->dev.has_prim_xf = 0u;
+    for (uint32_t i = 0; i < d->n_prims; i++)
+        if ((d->prim_meta[i].flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) s->dev.has_prim_xf = 1u;
     if (hipMalloc(reinterpret_cast<void **>(&s->status), RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess ||
         hipMemset(s->status, 0, RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess) {
         rtmi_scene_destroy(s);
@@ -563,7 +570,7 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
     // persistent grid: as many wavefronts as the kernel instantiation keeps resident (4 SIMDs x its waves per SIMD)
     const uint32_t wps_req = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
-    const uint32_t wps_run = (coop && !prof && !sigf && (wps_req == 3u || wps_req == 5u)) ? wps_req : (coop && prof ? 3u : 4u);
+    const uint32_t wps_run = (coop && !prof && !sigf && !s->dev.has_prim_xf && (wps_req == 3u || wps_req == 5u)) ? wps_req : (coop && prof ? 3u : 4u);
     const uint64_t run_slots = (uint64_t)(s->slots / 20) * 4u * wps_run;
     if (coop) {
         const size_t spill_bytes = (size_t)s->slots * P.spill_cap * sizeof(uint2);
@@ -590,21 +597,27 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     blocks_total += grid.x; chunks_total += P.nchunks;
     s->units_total += nitems;
 #define RTMI_LAUNCH(KERN, F, S, PR, LDS) hipLaunchKernelGGL((KERN<F, S, PR>), grid, block, LDS, stream, s->dev, C, P)
-#define RTMI_LAUNCH_COOP(S, PR, W, E)                                                                                    \
+#define RTMI_LAUNCH_COOP(S, PR, W, E, I)                                                                                 \
     do {                                                                                                                 \
         if (coop_lds > 48u * 1024u)                                                                                      \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi_render_coop<S, PR, W, E>),                  \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&rtmi_render_coop<S, PR, W, E, I>),               \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds));                     \
-        hipLaunchKernelGGL((rtmi_render_coop<S, PR, W, E>), grid, block, coop_lds, stream, s->dev, C, P);                \
+        hipLaunchKernelGGL((rtmi_render_coop<S, PR, W, E, I>), grid, block, coop_lds, stream, s->dev, C, P);             \
     } while (0)
     if (coop) {
         const uint32_t wps = wps_req;
-        if (prof) RTMI_LAUNCH_COOP(false, true, 3, true);
-        else if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true);
-        else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3, true);
-        else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5, true);
-        else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true);
-        else RTMI_LAUNCH_COOP(false, false, 4, false);
+        if (s->dev.has_prim_xf) { // scenes with instanced primitives: their own instantiations (no diagnostics builds)
+            if (prof) return fail(RTMI_ERR_UNSUPPORTED, "the profiling build has no instantiation for instanced primitives");
+            if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, true);
+            else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, true);
+            else RTMI_LAUNCH_COOP(false, false, 4, false, true);
+        }
+        else if (prof) RTMI_LAUNCH_COOP(false, true, 3, true, false);
+        else if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, false);
+        else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3, true, false);
+        else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5, true, false);
+        else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, false);
+        else RTMI_LAUNCH_COOP(false, false, 4, false, false);
     } else if (!async) {
         if (prof) { if (fast) RTMI_LAUNCH(rtmi_render_kernel, true, false, true, 0); else RTMI_LAUNCH(rtmi_render_kernel, false, false, true, 0); }
         else if (fast && sigf) RTMI_LAUNCH(rtmi_render_kernel, true, true, false, 0);

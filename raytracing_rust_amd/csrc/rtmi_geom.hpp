@@ -121,9 +121,11 @@ __device__ __forceinline__ bool sphere_test(const RayF &r, F3 c, float radius, f
     // select form (r03): both roots are evaluated and the first one inside (t_min, t_max) is kept, as sphere.rs:44-74
     // does with two early returns; the same comparisons on the same values (sqrt of a non-positive discriminant gives
     // NaN or 0 and is masked by disc > 0), without the three nested exec-mask regions
+    const bool pos = disc > 0.0f;
+    // (a wave-uniform skip of the square root when no lane has disc > 0 measured -0.5 % on final_scene, +0.2 % on
+    // random_spheres: profiles/r03_experiments/sph_ab.log — not kept)
     const float sq = __builtin_sqrtf(disc);
     const float t1 = (-b - sq) * r.inv_a, t2 = (-b + sq) * r.inv_a;
-    const bool pos = disc > 0.0f;
     const bool ok1 = pos & (t1 < t_max) & (t1 > t_min);
     const bool ok2 = pos & (t2 < t_max) & (t2 > t_min);
     t_out = ok1 ? t1 : (ok2 ? t2 : t_out);
@@ -236,13 +238,29 @@ __device__ __forceinline__ bool cube_test(float4 A, float4 B, const RayF &r, flo
 #endif
 }
 
+// Instanced primitive (rtmi.h, RTMI_PRIMFLAG_XF_*): the ray of the surrounding frame taken into the primitive's own
+// frame through its chain — Traslate::hit / Rotate::hit (traslate.rs:18-20, rotate.rs:85-92) — with the per-frame
+// derived values renewed when a rotation changed the direction.  t is the same in every frame.
+__device__ __forceinline__ RayF prim_frame(const rtmi_xform *xf, uint32_t flags, const RayF &r) {
+    RayF L = r;
+    const int cnt = (int)((flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX);
+    if (xform_ray(xf, (int)(flags >> RTMI_PRIMFLAG_XF_FIRST_SHIFT), cnt, L.o, L.d)) ray_derive(L);
+    return L;
+}
+#define RTMI_PRIM_HAS_XF(flags) ((((flags) >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) != 0u)
+
 // one primitive against (t_min, t_max); pf = prim << 3 | face.  The three planes are loaded up
 // front (independent addresses): one memory latency instead of up to three dependent ones.
-__device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx, const RayF &r, float time,
+// INST = false: an instantiation for scenes without instanced primitives (the cooperative kernel's headline build keeps
+// the transform code out of its traversal loop: inlined there it costs registers whether it runs or not)
+template <bool INST = true>
+__device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx, const RayF &r0, float time,
                                           float t_min, float t_max, float &t_out, int &pf) {
     const float4 A = sc.prim_a[idx];
     const float4 B = sc.prim_b[idx];
     const rtmi_prim_meta M = sc.meta[idx];
+    RayF r = r0;
+    if (INST && sc.has_prim_xf && RTMI_PRIM_HAS_XF(M.flags)) r = prim_frame(sc.xforms, M.flags, r0); // first test wave-uniform
     bool h = false;
     int face = 0;
     if (type == RTMI_PRIM_SPHERE) {
@@ -259,8 +277,11 @@ __device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx,
     return h;
 }
 // a primitive whose planes and meta words are at hand (leaf record of a gated tree)
-__device__ __forceinline__ bool prim_test_vals(int type, int idx, float4 A, float4 B, float m_inv_dt, uint32_t m_flags, const RayF &r,
-                                               float time, float t_min, float t_max, float &t_out, int &pf) {
+template <bool INST = true>
+__device__ __forceinline__ bool prim_test_vals(const DevScene &sc, int type, int idx, float4 A, float4 B, float m_inv_dt, uint32_t m_flags,
+                                               const RayF &r0, float time, float t_min, float t_max, float &t_out, int &pf) {
+    RayF r = r0;
+    if (INST && sc.has_prim_xf && RTMI_PRIM_HAS_XF(m_flags)) r = prim_frame(sc.xforms, m_flags, r0);
     bool h = false;
     int face = 0;
     if (type <= RTMI_PRIM_MSPHERE) {
@@ -279,12 +300,18 @@ __device__ __forceinline__ bool prim_test_vals(int type, int idx, float4 A, floa
     return h;
 }
 // the same for a wave-uniform primitive index (list items)
-__device__ __forceinline__ bool prim_test_uniform(const DevScene &sc, int idx, const RayF &r, float time,
+template <bool INST = true>
+__device__ __forceinline__ bool prim_test_uniform(const DevScene &sc, int idx, const RayF &r0, float time,
                                                   float t_min, float t_max, float &t_out, int &pf) {
     const float4 A = RTMI_UNIFORM_LOAD(float4, sc.prim_a + idx);
     const float4 B = RTMI_UNIFORM_LOAD(float4, sc.prim_b + idx);
     const rtmi_prim_meta M = RTMI_UNIFORM_LOAD(rtmi_prim_meta, sc.meta + idx);
     const int type = M.type;
+    RayF r = r0;
+    if (INST && RTMI_PRIM_HAS_XF(M.flags)) { // wave-uniform: the member of a nested list is wrapped in Traslate / Rotate
+        const int cnt = (int)((M.flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX);
+        if (xform_ray<true>(sc.xforms, (int)(M.flags >> RTMI_PRIMFLAG_XF_FIRST_SHIFT), cnt, r.o, r.d)) ray_derive(r);
+    }
     bool h = false;
     int face = 0;
     if (type == RTMI_PRIM_SPHERE) {

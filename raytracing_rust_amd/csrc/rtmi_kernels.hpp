@@ -139,7 +139,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
 // Same schedule as rtmi_render_kernel; the item scan of phase A is executed by ALL lanes (lanes
 // without a pending query are workers for the others' BVH traversals).
 // ----------------------------------------------------------------------------------
-template <bool SIG, bool PROF, int WPS, bool EXT>
+// INST: instantiation for scenes with instanced primitives (rtmi.h); the others carry no transform code in their loops
+template <bool SIG, bool PROF, int WPS, bool EXT, bool INST>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(DevScene sc, DevCamera cam, DevParams P) {
     __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
     unsigned long long *prof = prof_lds;
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                     float t;
                     int pf;
-                    if (geom_query_coop<PROF, EXT, EXT>(sc, I, P.use_alt != 0u, need, R, pa.rtime, P.t_min, closest, cw, t, pf, overflow, prof, slot)) {
+                    if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, P.use_alt != 0u, need, R, pa.rtime, P.t_min, closest, cw, t, pf, overflow, prof, slot)) {
                         closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                     }
                     prof_time<PROF>(prof, I.kind == RTMI_ITEM_BVH ? (it == 0 ? 27 : 28) : 26, tstamp);
@@ -225,8 +226,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         h1 = false; h2 = false;
                         if (need) sphere_two_queries(R, make_float4(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0]), h1, t1, h2, t2);
                     } else {
-                        h1 = geom_query_coop<PROF, EXT, false>(sc, I, P.use_alt != 0u, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
-                        h2 = geom_query_coop<PROF, EXT, false>(sc, I, P.use_alt != 0u, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
+                        h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, P.use_alt != 0u, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
+                        h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, P.use_alt != 0u, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
                     }
                     if (need && h1 && h2) {
                         if (medium_sample(t1, t2, P.t_min, closest, W.d, I.neg_inv_density, g, k0, k1, tm)) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             have_hit = false;
             if (SIG && shading) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
             // all lanes call (wavefront texture lookup); the traversal pool is idle now: LDS scratch
-            const bool goes_on = shade_hit(sc, P.max_depth, P.ext, g, k0, k1, shading, closest, best_item, best_pf, best_medium, pa,
+            const bool goes_on = shade_hit<decltype(g), INST>(sc, P.max_depth, P.ext, g, k0, k1, shading, closest, best_item, best_pf, best_medium, pa,
                                            reinterpret_cast<float *>(cw.wlds));
             if (shading && !goes_on) {
                 path_end(P, oidx, pa);

@@ -279,7 +279,7 @@ __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, f
 // ALL 64 lanes call this together (the texture lookup is a wavefront operation, tex_value_wave); lanes with
 // active = true hold a hit to shade.  Returns true when the lane's path continues (pa holds the scattered ray),
 // false when it ended (or the lane was not active).  `scratch`: 64 floats of LDS private to the wavefront.
-template <typename RngT>
+template <typename RngT, bool INST = true>
 __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth, uint32_t ext, RngT &g, uint32_t k0, uint32_t k1,
                                           bool active, float closest, int best_item, int best_pf, bool best_medium, Path &pa,
                                           float *scratch) {
@@ -311,6 +311,10 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
             const rtmi_prim_meta PM = sc.meta[idx];
             F3 lo = pa.ro, ld = pa.rd;
             if (xform_count > 0) xform_ray(sc.xforms, xform_first, xform_count, lo, ld);
+            // an instanced primitive's own chain, inside the item's frame (rtmi.h)
+            const int pxf_count = (INST && sc.has_prim_xf) ? (int)((PM.flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) : 0;
+            const int pxf_first = (int)(PM.flags >> RTMI_PRIMFLAG_XF_FIRST_SHIFT);
+            if (pxf_count > 0) xform_ray(sc.xforms, pxf_first, pxf_count, lo, ld);
             const bool needs_uv = (__float_as_uint(rec_mat.w) & RTMI_MATFLAG_NEEDS_UV) != 0u;
             hp = lo + ld * closest; // ray.pointing_at(t)
             if (PM.type == RTMI_PRIM_SPHERE || PM.type == RTMI_PRIM_MSPHERE) {
@@ -339,6 +343,7 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
                     hv = (y - y0) / (y1 - y0);
                 }
             }
+            if (pxf_count > 0) xform_hit(sc.xforms, pxf_first, pxf_count, hp, hn); // innermost frames first
             if (xform_count > 0) xform_hit(sc.xforms, xform_first, xform_count, hp, hn);
             if (((PM.flags ^ iflags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
         }

@@ -57,6 +57,7 @@ struct DevScene {
     const rtmi_image *images;
     const uint8_t *image_data;
     uint32_t n_items;
+    uint32_t has_prim_xf; // some primitive carries its own transform chain (instanced primitive, rtmi.h)
 };
 
 struct DevCamera {

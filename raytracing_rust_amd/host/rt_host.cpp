@@ -542,19 +542,61 @@ static const Hittable *strip_flips(const Hittable *h, bool &flip) {
     while (auto f = dynamic_cast<const FlipNormals *>(h)) { flip = !flip; h = f->inner().get(); }
     return h;
 }
+// Strips the wrappers a device PRIMITIVE may carry — FlipNormals (hittable.rs:67-88), Traslate (traslate.rs:6-9),
+// Rotate (rotate.rs:21-28), in any order and number — and returns the innermost object.  `chain` (optional) receives the
+// transforms outermost first, exactly as lower_item records an item's chain: Traslate<H> / Rotate<H> are generic over
+// any Hittable, so the reference lets them sit anywhere, e.g. as the children of a BVHNode (bvh.rs:11-12).
+static const Hittable *strip_wrappers(const Hittable *h, bool &flip, std::vector<rtmi_xform> *chain) {
+    for (;;) {
+        if (auto f = dynamic_cast<const FlipNormals *>(h)) { flip = !flip; h = f->inner().get(); continue; }
+        if (auto t = dynamic_cast<const Traslate *>(h)) {
+            if (chain) {
+                rtmi_xform x{};
+                x.kind = RTMI_XF_TRANSLATE; x.x = (float)t->offset_.x; x.y = (float)t->offset_.y; x.z = (float)t->offset_.z;
+                chain->push_back(x);
+            }
+            h = t->hitable_.get();
+            continue;
+        }
+        if (auto r = dynamic_cast<const Rotate *>(h)) {
+            if (chain) {
+                rtmi_xform x{};
+                x.kind = RTMI_XF_ROTATE_X + (int)r->axis_; x.x = (float)r->sin_theta_; x.y = (float)r->cos_theta_;
+                chain->push_back(x);
+            }
+            h = r->hittable_.get();
+            continue;
+        }
+        return h;
+    }
+}
+static bool is_device_primitive(const Hittable *h) {
+    return dynamic_cast<const Sphere *>(h) || dynamic_cast<const MovingSphere *>(h) || dynamic_cast<const Rect *>(h) ||
+           dynamic_cast<const Cube *>(h);
+}
 static bool contains_moving(const Hittable *h) {
     bool dummy = false;
-    h = strip_flips(h, dummy);
+    h = strip_wrappers(h, dummy, nullptr);
     if (dynamic_cast<const MovingSphere *>(h)) return true;
     if (auto n = dynamic_cast<const BVHNode *>(h)) return contains_moving(n->left_.get()) || contains_moving(n->right_.get());
     return false;
 }
 
 // one primitive -> planes A/B + meta; returns RTMI_LEAF-style type in the high bits of nothing: plain index
-int SceneBuilder::push_prim(const Hittable &h, bool flip, bool force_moving) {
+int SceneBuilder::push_prim(const Hittable &h0, bool flip, bool force_moving) {
     float A[4] = {0, 0, 0, 0}, B[4] = {0, 0, 0, 0};
     rtmi_prim_meta m{};
+    // an instanced primitive: its own Traslate / Rotate chain (outermost first) goes to `xforms`, referenced from the
+    // meta word; FlipNormals anywhere in the chain only toggles the flag (negation commutes with both)
+    std::vector<rtmi_xform> chain;
+    const Hittable &h = *strip_wrappers(&h0, flip, &chain);
     m.flags = flip ? RTMI_PRIMFLAG_FLIP : 0u;
+    if (!chain.empty()) {
+        if (chain.size() > RTMI_PRIM_XF_MAX) throw Unsupported("more than 15 Traslate/Rotate wrappers around one primitive");
+        if (out.xforms.size() + chain.size() >= (1u << 20)) throw Unsupported("too many instance transforms");
+        m.flags |= ((uint32_t)chain.size() << RTMI_PRIMFLAG_XF_COUNT_SHIFT) | ((uint32_t)out.xforms.size() << RTMI_PRIMFLAG_XF_FIRST_SHIFT);
+        out.xforms.insert(out.xforms.end(), chain.begin(), chain.end());
+    }
     m.inv_dt = 0.0f;
     if (auto s = dynamic_cast<const Sphere *>(&h)) {
         A[0] = (float)s->center_.x; A[1] = (float)s->center_.y; A[2] = (float)s->center_.z; A[3] = (float)s->radius_;
@@ -598,9 +640,15 @@ int SceneBuilder::push_prim(const Hittable &h, bool flip, bool force_moving) {
     return (int)out.prim_meta.size() - 1;
 }
 
+// f64 box -> fp32, one rounding; coordinates beyond the fp32 range (Rotate::bounding_box is the whole f64 space,
+// rotate.rs:36-37 — its update never fires) saturate at +-FLT_MAX: such a slab passes every ray in either precision
+static float sat_f32(double v) {
+    const double big = 3.40282346638528859811704183484516925e+38;
+    return v > big ? (float)big : (v < -big ? (float)-big : (float)v);
+}
 static void put_box(float mn[3], float mx[3], const AABB &b) {
-    mn[0] = (float)b.min.x; mn[1] = (float)b.min.y; mn[2] = (float)b.min.z;
-    mx[0] = (float)b.max.x; mx[1] = (float)b.max.y; mx[2] = (float)b.max.z;
+    mn[0] = sat_f32(b.min.x); mn[1] = sat_f32(b.min.y); mn[2] = sat_f32(b.min.z);
+    mx[0] = sat_f32(b.max.x); mx[1] = sat_f32(b.max.y); mx[2] = sat_f32(b.max.z);
 }
 
 // BVHNode -> rtmi_bvh_node records in preorder; leaves appended left to right (so the primitive
@@ -612,9 +660,42 @@ static void put_box(float mn[3], float mx[3], const AABB &b) {
 // geometry's real extent (a MovingSphere over its own [time0, time1]); contained() checks every node of a
 // BVH against it.  A BVH that fails is lowered with pruning disabled (item.scale = 1e30, unbounded leaf
 // boxes): the fast kernels then visit exactly what BVHNode::hit visits.
+static bool true_bounds_inner(const Hittable *h, AABB &out);
+// object -> world through a chain (outermost first), in f64: innermost wrapper first (traslate.rs:21-22, rotate.rs:94-105)
+static Vec3 chain_to_world(const std::vector<rtmi_xform> &chain, Vec3 p) {
+    for (size_t k = chain.size(); k-- > 0;) {
+        const rtmi_xform &X = chain[k];
+        if (X.kind == RTMI_XF_TRANSLATE) { p = p + Vec3(X.x, X.y, X.z); continue; }
+        const int r = X.kind - RTMI_XF_ROTATE_X, a = (r + 1) % 3, b = (r + 2) % 3;
+        const double s = X.x, c = X.y, pa = p[a], pb = p[b];
+        p[a] = c * pa - s * pb;
+        p[b] = s * pa + c * pb;
+    }
+    return p;
+}
 static bool true_bounds(const Hittable *h, AABB &out) {
     bool dummy = false;
-    h = strip_flips(h, dummy);
+    std::vector<rtmi_xform> chain;
+    const Hittable *inner = strip_wrappers(h, dummy, &chain);
+    AABB ib(Vec3(0, 0, 0), Vec3(0, 0, 0));
+    if (!true_bounds_inner(inner, ib)) return false;
+    if (chain.empty()) { out = ib; return true; }
+    // the box of the eight transformed corners (with the fp32 sines / cosines the device uses), widened by a relative
+    // 1e-6 for the fp32 rounding of the device's transforms: far inside the absolute padding every consumer adds
+    bool first = true;
+    for (int i = 0; i < 8; i++) {
+        const Vec3 c((i & 1) ? ib.max.x : ib.min.x, (i & 2) ? ib.max.y : ib.min.y, (i & 4) ? ib.max.z : ib.min.z);
+        const Vec3 w = chain_to_world(chain, c);
+        if (first) { out = AABB(w, w); first = false; }
+        else out = surrounding_box(out, AABB(w, w));
+    }
+    for (int k = 0; k < 3; k++) {
+        const double e = 1e-6 * std::fmax(std::fabs(out.min[k]), std::fabs(out.max[k]));
+        out.min[k] -= e; out.max[k] += e;
+    }
+    return true;
+}
+static bool true_bounds_inner(const Hittable *h, AABB &out) {
     if (auto r = dynamic_cast<const Rect *>(h)) {
         int k, a, b;
         plane_axes((int)r->plane_, k, a, b);
@@ -659,7 +740,7 @@ static bool contained(const BVHNode &n, double tol, AABB &out, bool &any) {
 }
 static void moving_time_range(const Hittable *h, float &lo, float &hi) {
     bool dummy = false;
-    h = strip_flips(h, dummy);
+    h = strip_wrappers(h, dummy, nullptr);
     if (auto m = dynamic_cast<const MovingSphere *>(h)) {
         lo = std::fmax(lo, (float)std::fmin(m->time0_, m->time1_));
         hi = std::fmin(hi, (float)std::fmax(m->time0_, m->time1_));
@@ -707,7 +788,9 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
             // the plane, rect.rs:72-73).
             const double big = 3.40282346638528859811704183484516925e+38;
             AABB lb(Vec3(-big, -big, -big), Vec3(big, big, big));
-            if (!unbounded_leaves && !dynamic_cast<const MovingSphere *>(h) && !dynamic_cast<const Rect *>(h)) {
+            bool dummy2 = false;
+            const Hittable *inner = strip_wrappers(h, dummy2, nullptr);
+            if (!unbounded_leaves && !dynamic_cast<const MovingSphere *>(inner) && !dynamic_cast<const Rect *>(inner)) {
                 // the primitive's TRUE extent (|radius| for a sphere), not bounding_box(): Sphere::bounding_box of a
                 // negative radius (the hollow-glass idiom) is an inverted box that no ray passes, and the reference has
                 // no leaf box test at all (bvh.rs:72-73)
@@ -903,9 +986,18 @@ void SceneBuilder::lower_item(const Hittable &top) {
         put_box(it.root_min, it.root_max, bvh->bbox_);
         double scale = 0.0;
         for (int k = 0; k < 3; k++) scale = std::fmax(scale, std::fmax(std::fabs(bvh->bbox_.min[k]), std::fabs(bvh->bbox_.max[k])));
-        if (!(scale < 1e30)) scale = 1e30;
         AABB tb(Vec3(0, 0, 0), Vec3(0, 0, 0));
         bool any = false;
+        if (!(scale < 1e30)) {
+            // a Rotate somewhere below makes every ancestor's box the whole space (rotate.rs:36-37): the margins of the
+            // pruned traversal then scale with the geometry's TRUE extent, not with 1.8e308
+            (void)contained(*bvh, 1e300, tb, any);
+            scale = 0.0;
+            if (any)
+                for (int k = 0; k < 3; k++) scale = std::fmax(scale, std::fmax(std::fabs(tb.min[k]), std::fabs(tb.max[k])));
+            if (!any || !(scale < 1e30)) scale = 1e30;
+            any = false;
+        }
         const bool prunable = contained(*bvh, scale / 65536.0, tb, any);
         it.scale = prunable ? (float)scale : 1e30f; // 1e30: the pruning margin swallows every distance
         const size_t prim_begin = out.prim_meta.size();

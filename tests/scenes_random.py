@@ -62,9 +62,23 @@ def _wrap(api, rng, h, allow_flip=True):
     return h
 
 
-def random_scene(api, seed, only=None):
-    """only: indices of the top-level items to keep (debugging aid; construction is identical either way)."""
+def random_scene(api, seed, only=None, instanced=False):
+    """only: indices of the top-level items to keep (debugging aid; construction is identical either way).
+    instanced: members of nested lists and children of BVHNodes are themselves wrapped in Traslate / Rotate /
+    FlipNormals chains with probability 0.4 (Traslate<H> / Rotate<H> are generic: traslate.rs:6-9, rotate.rs:21-28
+    under bvh.rs:11-12); the wrap decisions draw from their own generator, so instanced=False builds the same scenes as
+    before."""
     rng = np.random.default_rng(seed)
+    rng2 = np.random.default_rng(seed + 77_777)
+
+    def inst(p):
+        if instanced and rng2.random() < 0.4:
+            q = p
+            while q is p:  # at least one wrapper
+                q = _wrap(api, rng2, p)
+            return q
+        return p
+
     api.seed_scene_rng(seed)
     real = api.HittableList()
 
@@ -87,7 +101,7 @@ def random_scene(api, seed, only=None):
         elif k < 5:  # a nested list
             inner = api.HittableList()
             for _ in range(int(rng.integers(2, 5))):
-                p = _prim(api, rng)
+                p = inst(_prim(api, rng))
                 inner.push(api.FlipNormals(p) if rng.random() < 0.2 else p)
             world.push(_wrap(api, rng, inner))
         elif k < 8:  # a BVH (moving spheres make every static sphere in it a moving one on the device)
@@ -95,7 +109,7 @@ def random_scene(api, seed, only=None):
             moving = rng.random() < 0.4
             objs = []
             for _ in range(n):
-                p = _prim(api, rng, extent=2.5, allow_moving=moving)
+                p = inst(_prim(api, rng, extent=2.5, allow_moving=moving))
                 objs.append(api.FlipNormals(p) if rng.random() < 0.1 else p)
             if n > 6 and rng.random() < 0.3:  # a BVH built earlier as one of the objects of this one
                 inner = api.BVHNode(objs[:n // 2], 0.0, 1.0)
@@ -120,5 +134,5 @@ def random_camera(api, seed, nx, ny):
                       aperture, float(np.linalg.norm(look_from)), 0.0, 1.0)
 
 
-def build(api, seed, nx, ny, only=None):
-    return random_camera(api, seed, nx, ny), random_scene(api, seed, only)
+def build(api, seed, nx, ny, only=None, instanced=False):
+    return random_camera(api, seed, nx, ny), random_scene(api, seed, only, instanced)

@@ -100,9 +100,13 @@ def test_unsupported_nesting_fails_loudly(host):
     inner = host.ConstantMedium(host.Sphere((0, 0, 0), 1.0, mat), 0.1, tex)
     with pytest.raises(Unsupported):
         host.lower(host.Traslate(inner, (1, 0, 0)))  # medium inside a transform
-    nested = host.BVHNode([host.Traslate(host.Sphere((0, 0, 0), 1.0, mat), (1, 0, 0)), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0)
+    # (an instanced PRIMITIVE as a BVH leaf lowers since r03: tests/test_random_scenes.py)
+    sub = host.BVHNode([host.Sphere((0, 0, 0), 1.0, mat), host.Sphere((0, 2, 0), 1.0, mat)], 0.0, 1.0)
+    nested = host.BVHNode([host.Traslate(sub, (1, 0, 0)), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0)
     with pytest.raises(Unsupported):
-        host.lower(nested)  # instanced object as a BVH leaf
+        host.lower(nested)  # an instanced BVH as a BVH leaf
+    with pytest.raises(Unsupported):
+        host.lower(host.BVHNode([host.Traslate(inner, (1, 0, 0)), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0))  # a medium as a BVH leaf
     with pytest.raises(Unsupported):
         host.lower(host.HittableList())  # empty world
 

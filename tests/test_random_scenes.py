@@ -18,11 +18,12 @@ if os.environ.get("RTMI_RANDOM_SEEDS"):  # e.g. "25-200": an ad-hoc wider sweep
 TOL = 1e-4  # north star: per-channel linear radiance
 
 
+@pytest.mark.parametrize("instanced", [False, True], ids=["plain", "instanced"])
 @pytest.mark.parametrize("seed", SEEDS[:12])
-def test_mirror_equals_f64_oracle_and_lowers(host, orc64, seed):
+def test_mirror_equals_f64_oracle_and_lowers(host, orc64, seed, instanced):
     nx, ny = 16, 12
-    cam, world = scenes_random.build(host, seed, nx, ny)
-    camo, worldo = scenes_random.build(orc64, seed, nx, ny)
+    cam, world = scenes_random.build(host, seed, nx, ny, instanced=instanced)
+    camo, worldo = scenes_random.build(orc64, seed, nx, ny, instanced=instanced)
     row = 5
     ref = orc64.render(camo, worldo, nx, ny, 1, seed=42, rows=(row, row + 1))
     for i in range(nx):
@@ -34,12 +35,15 @@ def test_mirror_equals_f64_oracle_and_lowers(host, orc64, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("instanced", [False, True], ids=["plain", "instanced"])
 @pytest.mark.parametrize("seed", SEEDS)
-def test_device_equals_fp32_oracle_on_random_scenes(host, orc32, seed):
+def test_device_equals_fp32_oracle_on_random_scenes(host, orc32, seed, instanced):
+    """instanced: members of nested lists and BVH leaves wrapped in their own Traslate / Rotate / FlipNormals chains
+    (reference: traslate.rs:17-24, rotate.rs:84-113 under bvh.rs:11-12)."""
     nx, ny, ns = 40, 24, 6
-    cam, world = scenes_random.build(host, seed, nx, ny)
+    cam, world = scenes_random.build(host, seed, nx, ny, instanced=instanced)
     sc = host.lower(world)
-    camo, worldo = scenes_random.build(orc32, seed, nx, ny)
+    camo, worldo = scenes_random.build(orc32, seed, nx, ny, instanced=instanced)
     sky = SKY if seed % 3 == 0 else 0
     ref = orc32.render(camo, worldo, nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM | sky)
     dsky = abi.RTMI_FLAG_SKY if sky else 0
@@ -55,6 +59,66 @@ def test_device_equals_fp32_oracle_on_random_scenes(host, orc32, seed):
         assert np.array_equal(got["rgb8"].astype(np.int32), ref["rgb"]), (seed, label)
         assert np.array_equal(got["sig"], ref["sig"]), (seed, label)
     print(seed, "mean radiance", float(np.nanmean(ref["linear"])), "items", len(sc.arrays()["items"]))
+    orc32.free_all()
+
+
+def _instanced_bvh_world(api):
+    """The book's idiom the reference's generic wrappers allow: boxes turned and moved one by one, then handed to
+    BVHNode::new (bvh.rs:17-66) — plus a translated moving sphere, a flipped translated rect and a nested list with a
+    rotated member."""
+    lamb = api.Lambertian(api.SolidTexture(0.6, 0.5, 0.4))
+    metal = api.Metal(api.SolidTexture(0.8, 0.8, 0.9), 0.1)
+    objs = []
+    for i in range(12):
+        cube = api.Cube((-0.4, -0.4, -0.4), (0.4, 0.3 + 0.05 * i, 0.4), lamb if i % 3 else metal)
+        axis = [api.AXIS_Y, api.AXIS_X, api.AXIS_Z][i % 3]
+        objs.append(api.Traslate(api.Rotate(axis, cube, 15.0 * i - 40.0), (-3.0 + 0.55 * i, 0.2 * (i % 4), -1.5 + 0.3 * (i % 5))))
+    objs.append(api.Traslate(api.MovingSphere((0.0, 0.0, 0.0), (0.3, 0.2, 0.0), 0.0, 1.0, 0.35, lamb), (1.0, 1.2, 1.0)))
+    objs.append(api.FlipNormals(api.Traslate(api.Rect(api.PLANE_XY, -1.0, -1.0, 1.0, 1.0, 0.0, lamb), (0.0, 0.5, -2.5))))
+    objs.append(api.Rotate(api.AXIS_Y, api.Traslate(api.Sphere((0.0, 0.0, 0.0), 0.5, api.Dielectric(1.5)), (2.0, 0.6, 0.0)), 30.0))
+    objs.append(api.Sphere((0.0, -100.5, 0.0), 100.0, lamb))
+    inner = api.HittableList()
+    inner.push(api.Rotate(api.AXIS_Z, api.Cube((-0.3, -0.3, -0.3), (0.3, 0.3, 0.3), metal), 25.0))
+    inner.push(api.Traslate(api.Sphere((0.0, 0.0, 0.0), 0.3, lamb), (0.0, 0.9, 0.0)))
+    w = api.HittableList()
+    w.push(api.Sphere((0.0, 9.0, 2.0), 3.0, api.DiffuseLight(api.SolidTexture(4.0, 4.0, 4.0))))
+    w.push(api.BVHNode(objs, 0.0, 1.0))
+    w.push(api.Traslate(inner, (-1.5, 1.6, 1.0)))
+    return w
+
+
+def test_instanced_primitives_lower_with_their_own_chains(host):
+    host.seed_scene_rng(1)
+    a = host.lower(_instanced_bvh_world(host)).arrays()
+    cnt = [(m.flags >> abi.RTMI_PRIMFLAG_XF_COUNT_SHIFT) & 15 for m in a["prim_meta"]]
+    assert sorted(set(cnt)) == [0, 1, 2] and cnt.count(2) >= 13
+    for m, c in zip(a["prim_meta"], cnt):
+        if c:
+            first = m.flags >> abi.RTMI_PRIMFLAG_XF_FIRST_SHIFT
+            assert first + c <= len(a["xforms"])
+    bvh = [it for it in a["items"] if it.kind == abi.ITEM_BVH][0]
+    # Rotate::bounding_box is the whole space (rotate.rs:36-37): the root box saturates, the margins scale with the
+    # geometry's true extent (the r = 100 ground sphere), and the alternative tree is still built
+    assert bvh.root_max[0] == np.float32(3.4028235e38) and bvh.scale < 1000.0 and bvh.alt_first >= 0
+
+
+@pytest.mark.gpu
+def test_instanced_bvh_leaves_match_the_fp32_oracle(host, orc32):
+    nx, ny, ns = 96, 64, 16
+    worlds, cams = [], []
+    for api in (host, orc32):
+        api.seed_scene_rng(1)
+        worlds.append(_instanced_bvh_world(api))
+        cams.append(api.Camera((4.0, 3.0, 7.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 40.0, nx / ny, 0.1, 8.0, 0.0, 1.0))
+    sc = host.lower(worlds[0])
+    ref = orc32.render(cams[1], worlds[1], nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM)
+    assert float(ref["linear"].mean()) > 0.02
+    for flags in (0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_REF_TREE,
+                  abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL):
+        got = sc.render(cams[0], nx, ny, ns, seed=42, flags=flags, sig=True)
+        assert np.array_equal(got["sig"], ref["sig"]), flags
+        assert np.array_equal(got["linear"], ref["linear"]), flags
+        assert np.array_equal(got["rgb8"].astype(np.int32), ref["rgb"]), flags
     orc32.free_all()
 
 
