@@ -91,6 +91,13 @@ __device__ __forceinline__ void rng_init(RngReg &g, uint32_t sample, uint32_t pi
     g.block = 0; g.sample = sample; g.pixel = pixel; g.pos = 4;
 }
 __device__ __forceinline__ void rng_attach(RngReg &, uint32_t *) {}
+// Word selection (r03).  The n-th unread word of a lane sits at position pos + n of the sequence b0 b1 b2 b3 | n0 n1 n2
+// (current block, then the next one).  A chain "pos == 0 ? b0 : pos == 1 ? b1 : ..." is turned into a switch by the
+// compiler and lowered to nested exec-mask regions — dozens of scalar instructions per draw, in the innermost loop of the
+// rejection samplers.  Written as a two-stage barrel shifter on the bits of pos it stays a handful of v_cndmask:
+//   stage 1 (bit 0 of pos): y[i] = x[i + 1] or x[i];  stage 2 (bit 1): z[i] = y[i + 2] or y[i];  pos == 4: the new block.
+#define RTMI_SEL(c, a, b) ((c) ? (a) : (b))
+
 // rng.gen::<f64>() of the reference (24-bit uniform, rtmi_u01)
 __device__ __forceinline__ float rng_uniform(RngReg &g, uint32_t k0, uint32_t k1) {
     if (g.pos == 4) {
@@ -98,7 +105,9 @@ __device__ __forceinline__ float rng_uniform(RngReg &g, uint32_t k0, uint32_t k1
         g.block++;
         g.pos = 0;
     }
-    uint32_t w = g.pos == 0 ? g.b0 : (g.pos == 1 ? g.b1 : (g.pos == 2 ? g.b2 : g.b3));
+    const bool bit0 = (g.pos & 1u) != 0u, bit1 = (g.pos & 2u) != 0u;
+    const uint32_t y0 = RTMI_SEL(bit0, g.b1, g.b0), y1 = RTMI_SEL(bit0, g.b3, g.b2);
+    const uint32_t w = RTMI_SEL(bit1, y1, y0);
     g.pos++;
     return rtmi_u01(w);
 }
@@ -110,27 +119,33 @@ __device__ __forceinline__ float rng_uniform(RngReg &g, uint32_t k0, uint32_t k1
 __device__ __forceinline__ void rng_take3(RngReg &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1, uint32_t &w2) {
     uint32_t n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
     const uint32_t pos = g.pos;
-    if (pos >= 2u) { // fewer than three words left in the current block
+    const bool need = pos >= 2u; // fewer than three words left in the current block
+    if (need) {
         philox(g.block, g.sample, g.pixel, 0u, k0, k1, n0, n1, n2, n3);
         g.block++;
     }
-    w0 = pos == 0u ? g.b0 : (pos == 1u ? g.b1 : (pos == 2u ? g.b2 : (pos == 3u ? g.b3 : n0)));
-    w1 = pos == 0u ? g.b1 : (pos == 1u ? g.b2 : (pos == 2u ? g.b3 : (pos == 3u ? n0 : n1)));
-    w2 = pos == 0u ? g.b2 : (pos == 1u ? g.b3 : (pos == 2u ? n0 : (pos == 3u ? n1 : n2)));
-    if (pos >= 2u) { g.b0 = n0; g.b1 = n1; g.b2 = n2; g.b3 = n3; g.pos = pos - 1u; } // 2->1, 3->2, 4->3
-    else g.pos = pos + 3u;
+    const bool bit0 = (pos & 1u) != 0u, bit1 = (pos & 2u) != 0u, full = pos == 4u;
+    const uint32_t y0 = RTMI_SEL(bit0, g.b1, g.b0), y1 = RTMI_SEL(bit0, g.b2, g.b1), y2 = RTMI_SEL(bit0, g.b3, g.b2),
+                   y3 = RTMI_SEL(bit0, n0, g.b3), y4 = RTMI_SEL(bit0, n1, n0);
+    const uint32_t z0 = RTMI_SEL(bit1, y2, y0), z1 = RTMI_SEL(bit1, y3, y1), z2 = RTMI_SEL(bit1, y4, y2);
+    w0 = RTMI_SEL(full, n0, z0); w1 = RTMI_SEL(full, n1, z1); w2 = RTMI_SEL(full, n2, z2);
+    g.b0 = RTMI_SEL(need, n0, g.b0); g.b1 = RTMI_SEL(need, n1, g.b1); g.b2 = RTMI_SEL(need, n2, g.b2); g.b3 = RTMI_SEL(need, n3, g.b3);
+    g.pos = need ? pos - 1u : pos + 3u; // 2->1, 3->2, 4->3 in the new block
 }
 __device__ __forceinline__ void rng_take2(RngReg &g, uint32_t k0, uint32_t k1, uint32_t &w0, uint32_t &w1) {
     uint32_t n0 = 0u, n1 = 0u, n2 = 0u, n3 = 0u;
     const uint32_t pos = g.pos;
-    if (pos >= 3u) {
+    const bool need = pos >= 3u;
+    if (need) {
         philox(g.block, g.sample, g.pixel, 0u, k0, k1, n0, n1, n2, n3);
         g.block++;
     }
-    w0 = pos == 0u ? g.b0 : (pos == 1u ? g.b1 : (pos == 2u ? g.b2 : (pos == 3u ? g.b3 : n0)));
-    w1 = pos == 0u ? g.b1 : (pos == 1u ? g.b2 : (pos == 2u ? g.b3 : (pos == 3u ? n0 : n1)));
-    if (pos >= 3u) { g.b0 = n0; g.b1 = n1; g.b2 = n2; g.b3 = n3; g.pos = pos - 2u; } // 3->1, 4->2
-    else g.pos = pos + 2u;
+    const bool bit0 = (pos & 1u) != 0u, bit1 = (pos & 2u) != 0u, full = pos == 4u;
+    const uint32_t y0 = RTMI_SEL(bit0, g.b1, g.b0), y1 = RTMI_SEL(bit0, g.b2, g.b1), y2 = RTMI_SEL(bit0, g.b3, g.b2), y3 = RTMI_SEL(bit0, n0, g.b3);
+    const uint32_t z0 = RTMI_SEL(bit1, y2, y0), z1 = RTMI_SEL(bit1, y3, y1);
+    w0 = RTMI_SEL(full, n0, z0); w1 = RTMI_SEL(full, n1, z1);
+    g.b0 = RTMI_SEL(need, n0, g.b0); g.b1 = RTMI_SEL(need, n1, g.b1); g.b2 = RTMI_SEL(need, n2, g.b2); g.b3 = RTMI_SEL(need, n3, g.b3);
+    g.pos = need ? pos - 2u : pos + 2u; // 3->1, 4->2
 }
 
 
