@@ -92,6 +92,15 @@ fn chain_to_world(chain: &[RtmiXform], mut p: [f64; 3]) -> [f64; 3] {
     }
     p
 }
+/// A primitive that can never report a hit: a Rect with x0 > x1 or y0 > y1 (rect.rs:51).  Its test has no side effect,
+/// so such members of a list scan are left out of the flat scene (rt_host.cpp never_hit).
+fn never_hit(h: &Rc<HittableDesc>) -> bool {
+    let mut dummy = false;
+    match &**strip_wrappers(h, &mut dummy, None) {
+        HittableDesc::Rect { x0, y0, x1, y1, .. } => x0 > x1 || y0 > y1,
+        _ => false,
+    }
+}
 fn contains_moving(h: &Rc<HittableDesc>) -> bool {
     let mut dummy = false;
     match &**strip_wrappers(h, &mut dummy, None) {
@@ -702,6 +711,9 @@ impl SceneBuilder {
                 for e in list {
                     let mut f2 = false;
                     let p = strip_flips(e, &mut f2);
+                    if never_hit(p) {
+                        continue; // left out of the scan
+                    }
                     self.push_prim(p, f2, false)?;
                     it.count += 1;
                 }
@@ -711,6 +723,9 @@ impl SceneBuilder {
                 // A run of consecutive plain primitives of the world list (no transform, no medium) becomes ONE list
                 // item: scanned in order with the shrinking t_max exactly as items are (hittable.rs:37-47).
                 if !medium && it.xform_count == 0 {
+                    if never_hit(prim) {
+                        return Ok(()); // left out of the scan; the run goes on
+                    }
                     if let Some(ri) = self.run_item {
                         let (first, count) = (self.out.items[ri].first, self.out.items[ri].count);
                         if (first + count) as usize == self.out.prim_meta.len() {

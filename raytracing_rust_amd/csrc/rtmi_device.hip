@@ -266,7 +266,15 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
                 it.root_max[0] = d->prim_a[(size_t)it.first * 4 + 3];
             }
         }
-        rc = upload(s, items.data(), d->n_items, &s->dev.items);
+        std::vector<DevItem> ditems(d->n_items);
+        for (uint32_t i = 0; i < d->n_items; i++) {
+            DevItem &D = ditems[i];
+            memset(&D, 0, sizeof(D));
+            D.it = items[i];
+            if (items[i].xform_count > 0) D.x0 = d->xforms[items[i].xform_first];     // ranges checked by validate()
+            if (items[i].xform_count > 1) D.x1 = d->xforms[items[i].xform_first + 1];
+        }
+        rc = upload(s, ditems.data(), d->n_items, &s->dev.items);
     }
     if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_a), d->n_prims, &s->dev.prim_a);
     if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(d->prim_b), d->n_prims, &s->dev.prim_b);

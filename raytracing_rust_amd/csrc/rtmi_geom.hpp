@@ -44,6 +44,36 @@ __device__ __forceinline__ bool xform_ray(const rtmi_xform *xf, int first, int c
     }
     return rotated;
 }
+// one transform, world -> object (traslate.rs:18-20, rotate.rs:85-92); returns true for a rotation
+__device__ __forceinline__ bool xform_ray_one(const rtmi_xform &X, F3 &o, F3 &d) {
+    switch (X.kind) {
+    case RTMI_XF_TRANSLATE: o = o - f3(X.x, X.y, X.z); return false;
+    case RTMI_XF_ROTATE_X: rot_fwd(X.x, X.y, o.y, o.z); rot_fwd(X.x, X.y, d.y, d.z); return true;
+    case RTMI_XF_ROTATE_Y: rot_fwd(X.x, X.y, o.z, o.x); rot_fwd(X.x, X.y, d.z, d.x); return true;
+    default: rot_fwd(X.x, X.y, o.x, o.y); rot_fwd(X.x, X.y, d.x, d.y); return true;
+    }
+}
+__device__ __forceinline__ void xform_hit_one(const rtmi_xform &X, F3 &p, F3 &n) {
+    switch (X.kind) {
+    case RTMI_XF_TRANSLATE: p = p + f3(X.x, X.y, X.z); break;
+    case RTMI_XF_ROTATE_X: rot_inv(X.x, X.y, p.y, p.z); rot_inv(X.x, X.y, n.y, n.z); break;
+    case RTMI_XF_ROTATE_Y: rot_inv(X.x, X.y, p.z, p.x); rot_inv(X.x, X.y, n.z, n.x); break;
+    default: rot_inv(X.x, X.y, p.x, p.y); rot_inv(X.x, X.y, n.x, n.y); break;
+    }
+}
+// An item's chain with its first two transforms at hand (DevItem): same operations in the same order as xform_ray /
+// xform_hit over xforms[first .. first + count)
+template <bool UNIFORM = false>
+__device__ __forceinline__ bool xform_ray_item(const rtmi_xform *xf, int first, int count, const rtmi_xform &X0, const rtmi_xform &X1,
+                                               F3 &o, F3 &d) {
+    bool rotated = false;
+    if (count > 0) rotated = xform_ray_one(X0, o, d);
+    if (count > 1) rotated = xform_ray_one(X1, o, d) || rotated;
+    if (count > 2) rotated = xform_ray<UNIFORM>(xf, first + 2, count - 2, o, d) || rotated;
+    return rotated;
+}
+__device__ __forceinline__ void xform_hit_item(const rtmi_xform *xf, int first, int count, const rtmi_xform &X0, const rtmi_xform &X1,
+                                               F3 &p, F3 &n);
 // object -> world for the hit point and normal (innermost wrapper first)
 __device__ __forceinline__ void xform_hit(const rtmi_xform *xf, int first, int count, F3 &p, F3 &n) {
     for (int k = count - 1; k >= 0; k--) {
@@ -55,6 +85,13 @@ __device__ __forceinline__ void xform_hit(const rtmi_xform *xf, int first, int c
         default: rot_inv(X.x, X.y, p.x, p.y); rot_inv(X.x, X.y, n.x, n.y); break;
         }
     }
+}
+
+__device__ __forceinline__ void xform_hit_item(const rtmi_xform *xf, int first, int count, const rtmi_xform &X0, const rtmi_xform &X1,
+                                               F3 &p, F3 &n) {
+    if (count > 2) xform_hit(xf, first + 2, count - 2, p, n);
+    if (count > 1) xform_hit_one(X1, p, n);
+    if (count > 0) xform_hit_one(X0, p, n);
 }
 
 // ----------------------------------------------------------------------------------

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                 closest = RTMI_FLT_MAX;
                 best_item = -1; best_pf = 0; best_medium = false;
                 for (uint32_t it = 0; it < sc.n_items; it++) {
-                    const rtmi_item I = sc.items[it];
+                    const rtmi_item I = sc.items[it].it;
                     RayF R = W;
                     if (I.xform_count > 0) {
                         if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
@@ -201,10 +201,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
             for (uint32_t it = 0; it < sc.n_items; it++) { // executed by all 64 lanes
-                const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, sc.items + it);
+                const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
                 RayF R = W;
-                if (I.xform_count > 0) {
-                    if (xform_ray<true>(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
+                if (I.xform_count > 0) { // both transforms of a chain of two in ONE scalar fetch (they follow the item record)
+                    struct XPair { rtmi_xform x0, x1; };
+                    const XPair XP = RTMI_UNIFORM_LOAD(XPair, reinterpret_cast<const XPair *>(&sc.items[it].x0));
+                    if (xform_ray_item<true>(sc.xforms, I.xform_first, I.xform_count, XP.x0, XP.x1, R.o, R.d)) ray_derive(R);
                 }
                 const int slot = 1 + (it < 11u ? (int)it : 11);
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                         } else {
                             if (have) {
                                 float tm;
-                                if (medium_sample(t1, bt, P.t_min, closest, W.d, sc.items[it].neg_inv_density, g, k0, k1, tm)) {
+                                if (medium_sample(t1, bt, P.t_min, closest, W.d, sc.items[it].it.neg_inv_density, g, k0, k1, tm)) {
                                     closest = tm; best_item = it; best_medium = true;
                                 }
                             }
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                         break;
                     }
                     // ---- enter item `it`
-                    const rtmi_item I = sc.items[it];
+                    const rtmi_item I = sc.items[it].it;
                     iflags = I.flags;
                     R = W;
                     if (I.xform_count > 0) {

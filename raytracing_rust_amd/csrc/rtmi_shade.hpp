@@ -294,7 +294,10 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
     if (active) {
         // of the item only {flags, xform_first, xform_count, medium_material} are needed: one 16-B fetch
         struct __attribute__((aligned(4))) ItemWords { int x, y, z, w; }; // 4-byte aligned: offset 12 of a 64-B record
-        const ItemWords IW = *reinterpret_cast<const ItemWords *>(reinterpret_cast<const char *>(sc.items + best_item) + 12);
+        const char *ditem = reinterpret_cast<const char *>(sc.items + best_item);
+        const ItemWords IW = *reinterpret_cast<const ItemWords *>(ditem + 12);
+        // the item's first two transforms travel with it (DevItem): no fetch that depends on IW
+        const rtmi_xform IX0 = *reinterpret_cast<const rtmi_xform *>(ditem + 64), IX1 = *reinterpret_cast<const rtmi_xform *>(ditem + 80);
         const uint32_t iflags = (uint32_t)IW.x;
         const int xform_first = IW.y, xform_count = IW.z;
         float4 rec_mat, rec_t0, rec_t1; // material record + its texture record, fetched with the hit's geometry
@@ -309,8 +312,9 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
             const float4 A = rec[0];
             rec_mat = rec[1]; rec_t0 = rec[2]; rec_t1 = rec[3];
             const rtmi_prim_meta PM = sc.meta[idx];
+            const float4 PB = sc.prim_b[idx]; // fetched with the rest, not after the type is known (one latency, not two)
             F3 lo = pa.ro, ld = pa.rd;
-            if (xform_count > 0) xform_ray(sc.xforms, xform_first, xform_count, lo, ld);
+            if (xform_count > 0) xform_ray_item(sc.xforms, xform_first, xform_count, IX0, IX1, lo, ld);
             // an instanced primitive's own chain, inside the item's frame (rtmi.h)
             const int pxf_count = (INST && sc.has_prim_xf) ? (int)((PM.flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) : 0;
             const int pxf_first = (int)(PM.flags >> RTMI_PRIMFLAG_XF_FIRST_SHIFT);
@@ -319,7 +323,7 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
             hp = lo + ld * closest; // ray.pointing_at(t)
             if (PM.type == RTMI_PRIM_SPHERE || PM.type == RTMI_PRIM_MSPHERE) {
                 F3 c = f3(A.x, A.y, A.z);
-                if (PM.type == RTMI_PRIM_MSPHERE) c = moving_center(A, sc.prim_b[idx], PM.inv_dt, pa.rtime);
+                if (PM.type == RTMI_PRIM_MSPHERE) c = moving_center(A, PB, PM.inv_dt, pa.rtime);
                 hn = vdiv(hp - c, A.w); // sphere.rs:50 — outward, never face-forwarded
                 if (needs_uv) sphere_uv(hn, (ext & RTMI_EXT_UV_BOOK) != 0u, hu, hv);
             } else {
@@ -329,8 +333,7 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
                     plane = (int)((PM.flags >> RTMI_PRIMFLAG_PLANE_SHIFT) & 3u);
                     x0 = A.x; y0 = A.y; x1 = A.z; y1 = A.w;
                 } else { // cube face -> its rect (cube.rs:21-74)
-                    const float4 B = sc.prim_b[idx];
-                    const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
+                    const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = PB.x, bz = PB.y;
                     if (face < 2) { plane = 2; x0 = ax; y0 = ay; x1 = bx; y1 = by; }
                     else if (face < 4) { plane = 1; x0 = az; y0 = ax; x1 = bz; y1 = bx; }
                     else { plane = 0; x0 = ay; y0 = az; x1 = by; y1 = bz; }
@@ -344,7 +347,7 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
                 }
             }
             if (pxf_count > 0) xform_hit(sc.xforms, pxf_first, pxf_count, hp, hn); // innermost frames first
-            if (xform_count > 0) xform_hit(sc.xforms, xform_first, xform_count, hp, hn);
+            if (xform_count > 0) xform_hit_item(sc.xforms, xform_first, xform_count, IX0, IX1, hp, hn);
             if (((PM.flags ^ iflags) & 1u) != 0u) hn = -hn; // FlipNormals — hittable.rs:78-83
         }
 

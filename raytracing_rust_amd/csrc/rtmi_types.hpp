@@ -33,8 +33,17 @@ __device__ __forceinline__ float comp(F3 a) {
     return I == 0 ? a.x : (I == 1 ? a.y : a.z);
 }
 
+// Device copy of one world-list entry (built by rtmi_scene_create): the item record followed by the first two
+// transforms of its chain, so that neither the item loop (one scalar load sequence) nor the shading of a hit (one
+// dependent fetch) waits for `xforms` after the item record has arrived — final_scene's sphere BVH sits under
+// Traslate(Rotate(..)) and every one of its hits used to pay four serialised transform fetches.
+struct DevItem {
+    rtmi_item it;     // 64 B
+    rtmi_xform x0, x1; // xforms[it.xform_first], [.. + 1] (zeros when the chain is shorter)
+}; // 96 B
+
 struct DevScene {
-    const rtmi_item *items;
+    const DevItem *items;
     const float4 *prim_a;
     const float4 *prim_b;
     const rtmi_prim_meta *meta;

@@ -574,6 +574,15 @@ static bool is_device_primitive(const Hittable *h) {
     return dynamic_cast<const Sphere *>(h) || dynamic_cast<const MovingSphere *>(h) || dynamic_cast<const Rect *>(h) ||
            dynamic_cast<const Cube *>(h);
 }
+// A primitive that can never report a hit, whatever the ray: a Rect with x0 > x1 or y0 > y1 (rect.rs:51 rejects every
+// x) — final_scene's light is one (tests/test.rs:444-452).  Its test has no side effect (no random draw), so the
+// members of a list scan that can never be hit are left out of the flat scene: the scan returns what it returned.
+static bool never_hit(const Hittable *h) {
+    bool dummy = false;
+    h = strip_wrappers(h, dummy, nullptr);
+    if (auto r = dynamic_cast<const Rect *>(h)) return r->x0_ > r->x1_ || r->y0_ > r->y1_;
+    return false;
+}
 static bool contains_moving(const Hittable *h) {
     bool dummy = false;
     h = strip_wrappers(h, dummy, nullptr);
@@ -1020,6 +1029,7 @@ void SceneBuilder::lower_item(const Hittable &top) {
         for (const auto &e : list->items()) {
             bool f2 = false;
             const Hittable *p = strip_flips(e.get(), f2);
+            if (never_hit(p)) continue; // left out of the scan
             push_prim(*p, f2, false);
             it.count++;
         }
@@ -1028,6 +1038,7 @@ void SceneBuilder::lower_item(const Hittable &top) {
         // item: the device scans its primitives in order with the shrinking t_max exactly as it scans items
         // (hittable.rs:37-47), without the per-item overhead.  FlipNormals goes to the primitive's flag.
         if (!medium && it.xform_count == 0) {
+            if (never_hit(h)) return; // left out of the scan; the run goes on
             if (run_item_ >= 0) {
                 rtmi_item &run = out.items[(size_t)run_item_];
                 if (run.first + run.count == (int32_t)out.prim_meta.size()) {

@@ -31,9 +31,10 @@ def test_dump_layout_is_self_consistent():
     body = 64 * n_items + 16 * n_prims * 2 + 16 * n_prims + 32 * n_prims + 64 * n_nodes + 128 * n_alt + 16 * n_xf + 16 * n_mat + \
         32 * n_tex + 7168 * n_perlin + 16 * n_img
     assert len(data) == 76 + body
-    # final_scene as the reference builds it (tests/test.rs:419-523): 400 cubes + 9 top-level primitives (light rect,
-    # 5 spheres, 2 medium boundaries, ... ) + 1000 spheres; 11 world objects in 6 items (runs of plain primitives merge)
-    assert (n_items, n_prims, n_perlin, n_img, image_bytes) == (6, 1409, 1, 1, 1024 * 512 * 3)
+    # final_scene as the reference builds it (tests/test.rs:419-523): 400 cubes + 8 top-level primitives (5 spheres,
+    # 2 medium boundaries, ...; the light rect has x0 > x1, can never be hit (rect.rs:51) and is left out of the list scan)
+    # + 1000 spheres; 11 world objects in 6 items (runs of plain primitives merge)
+    assert (n_items, n_prims, n_perlin, n_img, image_bytes) == (6, 1408, 1, 1, 1024 * 512 * 3)
     # bvh.rs:44-45: a slice of one element becomes a node of its own, so there are more than N - 1 nodes
     assert n_nodes >= 399 + 999 and n_alt > 0 and depth <= 24 and alt_depth <= depth
     assert n_xf == 2  # Traslate(Rotate(Y, BVH)) (:517-522)
