@@ -18,7 +18,12 @@ __device__ __forceinline__ void philox(uint32_t c0, uint32_t c1, uint32_t c2, ui
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
         const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
         const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        // three-input XOR as ONE v_bitop3_b32 (truth table 0x96; gfx950 has no v_xor3): 2 instead of 4 per round
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+#else
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+#endif
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
@@ -155,8 +160,10 @@ __device__ __forceinline__ F3 random_in_unit_sphere(RngT &g, uint32_t k0, uint32
     for (;;) {
         uint32_t w0, w1, w2;
         rng_take3(g, k0, k1, w0, w1, w2);
-        const float x = rtmi_u01(w0), y = rtmi_u01(w1), z = rtmi_u01(w2);
-        F3 p = f3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 2.0f * z - 1.0f);
+        // 2u - 1 with u = k * 2^-24 (rtmi_u01) as ONE fma on the integer: k * 2^-23 and (2u) - 1 are both exact (a
+        // multiple of 2^-23 in [-1, 1)), so fma(k, 2^-23, -1) is the same value without the separate scaling
+        F3 p = f3(__builtin_fmaf((float)(w0 >> 8), 0x1.0p-23f, -1.0f), __builtin_fmaf((float)(w1 >> 8), 0x1.0p-23f, -1.0f),
+                  __builtin_fmaf((float)(w2 >> 8), 0x1.0p-23f, -1.0f));
         if (dot(p, p) < 1.0f) return p;
     }
 }
@@ -166,8 +173,7 @@ __device__ __forceinline__ F3 random_in_unit_disk(RngT &g, uint32_t k0, uint32_t
     for (;;) {
         uint32_t w0, w1;
         rng_take2(g, k0, k1, w0, w1);
-        const float x = rtmi_u01(w0), y = rtmi_u01(w1);
-        F3 p = f3(2.0f * x - 1.0f, 2.0f * y - 1.0f, 0.0f);
+        F3 p = f3(__builtin_fmaf((float)(w0 >> 8), 0x1.0p-23f, -1.0f), __builtin_fmaf((float)(w1 >> 8), 0x1.0p-23f, -1.0f), 0.0f);
         if (dot(p, p) < 1.0f) return p;
     }
 }

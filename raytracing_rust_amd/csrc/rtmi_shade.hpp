@@ -257,13 +257,15 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevPar
 // ConstantMedium::hit after both boundary queries — medium.rs:33-53.  Returns true when the
 // medium scatters before the boundary exit / the closest hit so far; the draw happens only when
 // the clamped interval is non-empty, as in the reference.
+// `dn` = |direction| of the WORLD ray (medium.rs:38 `ray.direction().norm()`), evaluated once per query by the caller
+// as sqrt(W.a): W.a is dot(d, d) already (ray_derive), the same expression norm() squares — same bits, and the two media
+// of final_scene share one square root per query instead of a dot product and a square root each.
 template <typename RngT>
-__device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, F3 world_d,
+__device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, float dn,
                                               float neg_inv_density, RngT &g, uint32_t k0, uint32_t k1, float &t_out) {
     if (t1 < t_min) t1 = t_min;
     if (t2 > closest) t2 = closest;
     if (t1 < t2) {
-        const float dn = norm(world_d);
         const float dist_inside = (t2 - t1) * dn;
         const float hit_distance = neg_inv_density * rtmi_logf(rng_uniform(g, k0, k1));
         if (hit_distance < dist_inside) {
