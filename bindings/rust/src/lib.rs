@@ -170,6 +170,16 @@ impl Scene {
     }
 }
 
+impl Scene {
+    /// RTMI_FLAG_PROGRESSIVE: the image of the passes finished so far of the `render` call running on this scene — only
+    /// from inside that call's progress callback.  Returns the samples per pixel the image holds (0 = nothing yet).
+    pub fn partial_image(&mut self, p: &RtmiRenderParams, img: &mut Image) -> Result<u32, RtmiError> {
+        let mut spp = 0u32;
+        check(unsafe { rtmi_partial_image(self.raw, p, img.linear.as_mut_ptr(), img.rgb8.as_mut_ptr(), &mut spp) })?;
+        Ok(spp)
+    }
+}
+
 impl Drop for Scene {
     fn drop(&mut self) {
         unsafe { rtmi_scene_destroy(self.raw) }

@@ -14,6 +14,8 @@ pub const RTMI_FLAG_SKY: u32 = 32;
 pub const RTMI_FLAG_REF_TREE: u32 = 64;
 pub const RTMI_FLAG_FACE_FORWARD: u32 = 128;
 pub const RTMI_FLAG_UV_BOOK: u32 = 4096;
+/// opt-in: after every pass the framebuffer holds the image of the samples so far (rtmi_partial_image)
+pub const RTMI_FLAG_PROGRESSIVE: u32 = 16384;
 pub const RTMI_OK: i32 = 0;
 pub const RTMI_ERR_INVALID: i32 = 1;
 pub const RTMI_ERR_UNSUPPORTED: i32 = 2;
@@ -297,6 +299,14 @@ extern "C" {
         out_rgb8: *mut u8,
         out_path_sig: *mut u64,
         stats: *mut RtmiStats,
+    ) -> c_int;
+    /// RTMI_FLAG_PROGRESSIVE: only from inside the progress callback of the rtmi_render call running on `scene`
+    pub fn rtmi_partial_image(
+        scene: *mut RtmiScene,
+        p: *const RtmiRenderParams,
+        out_linear_rgb: *mut f32,
+        out_rgb8: *mut u8,
+        spp_done: *mut u32,
     ) -> c_int;
     pub fn rtmi_untile(
         p: *const RtmiRenderParams,

@@ -223,6 +223,13 @@ typedef struct {
                                 * the geometric normal: it resolves the side itself (src/material.rs:106-114). */
 #define RTMI_FLAG_UV_BOOK 4096u /* get_sphere_uv with v = (theta + pi/2) / pi (the book's formula) instead of the
                                 * reference's FRAC_2_PI = 2/pi (src/sphere.rs:13), i.e. v in [0,1] */
+#define RTMI_FLAG_PROGRESSIVE 16384u /* opt-in (progressive output; the reference's stand-in is the
+                                * sleeping bar of src/progressbar.rs:6-58): after EVERY pass of the sample range the framebuffer
+                                * holds the image of the samples rendered so far — their mean in sample order, quantised like
+                                * the final image, i.e. exactly the image of a render with ns = samples so far — instead of only
+                                * after the last one.  A render runs in passes when sample_buffer_bytes is smaller than
+                                * 16 B x pixels x ns (a budget of K samples' worth gives passes of K samples).  With a progress
+                                * callback on rtmi_render, rtmi_partial_image() fetches that image from inside the callback. */
 #define RTMI_FLAG_TEST_OVERFLOW 8192u /* test knob: the cooperative kernel reports a traversal-pool overflow although
                                 * none happened, to exercise the error path (results of that call are poisoned) */
 typedef struct {
@@ -345,6 +352,14 @@ int rtmi_render_multi(const rtmi_scene_desc *desc, const int *devices, uint32_t 
 int rtmi_render(rtmi_scene *scene, const rtmi_camera *cam, const rtmi_render_params *p, float *out_linear_rgb,
                 uint8_t *out_rgb8, uint64_t *out_path_sig /* ny*nx, optional: sets RTMI_FLAG_PATH_SIG */,
                 rtmi_stats *stats);
+
+/* RTMI_FLAG_PROGRESSIVE: the image of the passes finished so far of the rtmi_render call running on `scene`.  To be
+ * called ONLY from inside that call's progress callback (same thread; it takes no lock and reads the handle's
+ * framebuffer through its copy stream).  *spp_done = samples per pixel the image holds (0: no pass has finished yet,
+ * the outputs are left untouched); pixels may come from two consecutive passes when a pass ends during the copy.
+ * `p` = the parameters of the running call (image size).  out_linear_rgb / out_rgb8 as for rtmi_render; may be NULL. */
+int rtmi_partial_image(rtmi_scene *scene, const rtmi_render_params *p, float *out_linear_rgb, uint8_t *out_rgb8,
+                       uint32_t *spp_done);
 
 /* Host-side un-tiling of `tile_world` gathered local buffers (rank-major, each
  * rtmi_local_tiles(rank 0)*64 texels, i.e. padded to the largest rank) into raster order. */

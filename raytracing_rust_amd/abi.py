@@ -24,6 +24,7 @@ RTMI_FLAG_REF_TREE = 64
 RTMI_FLAG_FACE_FORWARD = 128
 RTMI_FLAG_UV_BOOK = 4096
 RTMI_FLAG_TEST_OVERFLOW = 8192
+RTMI_FLAG_PROGRESSIVE = 16384  # opt-in: the framebuffer holds the image of the samples so far after every pass
 RTMI_ERR_DEVICE = 3
 RTMI_ERR_CANCELLED = 5
 RTMI_TEXEL_POISON = 0x80000000
@@ -123,7 +124,7 @@ class Stats(C.Structure):
 # every entry point include/rtmi.h declares (tests check that the library exports them all)
 RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_local_tiles",
                 "rtmi_render_prepare", "rtmi_render_device", "rtmi_scene_status", "rtmi_render", "rtmi_render_multi", "rtmi_multi_create",
-                "rtmi_multi_prepare", "rtmi_multi_render", "rtmi_multi_destroy", "rtmi_untile",
+                "rtmi_multi_prepare", "rtmi_multi_render", "rtmi_multi_destroy", "rtmi_partial_image", "rtmi_untile",
                 "rtmi_ppm_p3", "rtmi_write_ppm", "rtmi_probe_math", "rtmi_probe_philox", "rtmi_probe_xform"]
 
 _rtmi = None
@@ -167,6 +168,8 @@ def load_rtmi():
     lib.rtmi_multi_destroy.argtypes = [vp]
     lib.rtmi_render.restype = C.c_int
     lib.rtmi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
+    lib.rtmi_partial_image.restype = C.c_int
+    lib.rtmi_partial_image.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(C.c_uint32)]
     lib.rtmi_untile.restype = C.c_int
     lib.rtmi_untile.argtypes = [C.POINTER(RenderParams), vp, vp, vp]
     lib.rtmi_ppm_p3.restype = C.c_size_t
@@ -233,6 +236,7 @@ def load_host():
         "rth_render_prepare": (i, [vp, C.POINTER(RenderParams)]),
         "rth_scene_status": (i, [vp]),
         "rth_render_multi": (i, [vp, vp, C.POINTER(RenderParams), C.POINTER(C.c_int), u32, vp, vp, C.POINTER(Stats)]),
+        "rth_partial_image": (i, [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(C.c_uint32)]),
         "rth_upload_multi": (i, [vp, C.POINTER(C.c_int), u32]),
         "rth_multi_free": (i, [vp]),
         "rth_multi_prepare": (i, [vp, C.POINTER(RenderParams)]),

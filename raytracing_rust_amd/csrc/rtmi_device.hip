@@ -70,6 +70,8 @@ struct rtmi_scene {
     size_t sig_count = 0;
     rtmi_texel *h_texels = nullptr;    // pinned host mirror of `texels` (hipHostMalloc: the D2H copy runs at link speed)
     size_t h_texel_count = 0;
+    rtmi_texel *h_partial = nullptr;   // ... and of the partial images rtmi_partial_image fetches (RTMI_FLAG_PROGRESSIVE)
+    size_t h_partial_count = 0;
     std::vector<unsigned long long> h_sig;
     // Thread model (rtmi.h): render calls on one handle serialise.  `mu` orders the host side (planning, scratch
     // (re)allocation, enqueue, and for the blocking calls the wait and the copy-out); `busy` chains the device side: a
@@ -383,6 +385,7 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     if (s->d_sig) (void)hipFree(s->d_sig);
     if (s->status) (void)hipFree(s->status);
     if (s->h_texels) (void)hipHostFree(s->h_texels);
+    if (s->h_partial) (void)hipHostFree(s->h_partial);
     if (s->busy) (void)hipEventDestroy(s->busy);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
@@ -554,7 +557,7 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
             ((p->flags & RTMI_FLAG_TEST_OVERFLOW) ? RTMI_EXT_TEST_OVERFLOW : 0u);
     // this call's overflow word, the unit counter and the finished-units word start at zero; the sticky word stays
     HIP_TRY(hipMemsetAsync(s->status, 0, 2 * sizeof(unsigned int), stream));
-    HIP_TRY(hipMemsetAsync(s->status + 3, 0, sizeof(unsigned int), stream));
+    HIP_TRY(hipMemsetAsync(s->status + 3, 0, 2 * sizeof(unsigned int), stream));
     s->units_total = 0;
     // LDS part of the traversal stack: 512 entries cover the deepest stack ever seen on the reference scenes
     // (447); deeper stacks continue in global memory (64 * (depth + 2) entries per wavefront, the bound of the
@@ -645,8 +648,9 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     const bool last = s0 + P.pass_cnt >= p->ns;
     if (stats && last) HIP_TRY(hipEventRecord(s->ev[1], stream));
     hipLaunchKernelGGL(rtmi_resolve_kernel, dim3((ntex + 255) / 256), dim3(256), 0, stream, s->samples, s->partial,
-                       reinterpret_cast<rtmi_texel *>(d_texels), P, s0 == 0 ? 1 : 0, last ? 1 : 0);
-    hipLaunchKernelGGL(rtmi_pass_end_kernel, dim3(1), dim3(1), 0, stream, s->status, (unsigned int)nitems, last ? 1 : 0);
+                       reinterpret_cast<rtmi_texel *>(d_texels), P, s0 == 0 ? 1 : 0, last ? 1 : 0,
+                       (p->flags & RTMI_FLAG_PROGRESSIVE) ? 1 : 0);
+    hipLaunchKernelGGL(rtmi_pass_end_kernel, dim3(1), dim3(1), 0, stream, s->status, (unsigned int)nitems, P.pass_cnt, last ? 1 : 0);
     HIP_TRY(hipGetLastError());
     } // passes
     if (stats) {
@@ -759,7 +763,7 @@ static int wait_with_progress(rtmi_scene *const *scenes, hipEvent_t *done_ev, ui
                 const hipError_t q = hipEventQuery(done_ev[i]);
                 if (q == hipErrorNotReady) {
                     all_done = false;
-                    unsigned int w[RTMI_STATUS_WORDS] = {0, 0, 0, 0};
+                    unsigned int w[RTMI_STATUS_WORDS] = {0, 0, 0, 0, 0};
                     HIP_TRY(hipMemcpyAsync(w, s->status, sizeof(w), hipMemcpyDeviceToHost, s->copy_stream));
                     HIP_TRY(hipStreamSynchronize(s->copy_stream));
                     const uint64_t d = (uint64_t)w[3] + w[1]; // finished passes + units handed out in the running one
@@ -881,6 +885,35 @@ extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_ren
             }
     }
     return rtmi_untile(&p, s->h_texels, out_linear, out_rgb8);
+}
+
+// RTMI_FLAG_PROGRESSIVE: the framebuffer of the running rtmi_render call as it stands (called from its progress callback:
+// the calling thread holds s->mu, so none is taken here)
+extern "C" int rtmi_partial_image(rtmi_scene *s, const rtmi_render_params *p_in, float *out_linear, uint8_t *out_rgb8,
+                                  uint32_t *spp_done) {
+    if (!s || !spp_done) return fail(RTMI_ERR_INVALID, "NULL argument");
+    int rc = check_params(p_in);
+    if (rc) return rc;
+    if (p_in->tile_world != 1) return fail(RTMI_ERR_INVALID, "rtmi_partial_image serves rtmi_render: tile_world must be 1");
+    *spp_done = 0;
+    rtmi_render_params p = *p_in;
+    const size_t ntex = (size_t)rtmi_local_tiles(&p) * 64;
+    if (!s->texels || ntex > s->texel_count || !s->copy_stream) return fail(RTMI_ERR_INVALID, "no rtmi_render call of this size is running on the handle");
+    HIP_TRY(hipSetDevice(s->device));
+    if ((rc = ensure_host_texels(&s->h_partial, &s->h_partial_count, ntex))) return rc;
+    unsigned int w[RTMI_STATUS_WORDS] = {0, 0, 0, 0, 0}, w2[RTMI_STATUS_WORDS] = {0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(w, s->status, sizeof(w), hipMemcpyDeviceToHost, s->copy_stream));
+    HIP_TRY(hipStreamSynchronize(s->copy_stream));
+    if (w[4] == 0u) return RTMI_OK; // no pass has finished: nothing to show yet
+    for (int attempt = 0; attempt < 2; attempt++) { // a consistent snapshot unless passes end faster than the copy
+        HIP_TRY(hipMemcpyAsync(s->h_partial, s->texels, ntex * sizeof(rtmi_texel), hipMemcpyDeviceToHost, s->copy_stream));
+        HIP_TRY(hipMemcpyAsync(w2, s->status, sizeof(w2), hipMemcpyDeviceToHost, s->copy_stream));
+        HIP_TRY(hipStreamSynchronize(s->copy_stream));
+        if (w2[4] == w[4]) break;
+        w[4] = w2[4];
+    }
+    *spp_done = w[4] < p.ns ? w[4] : p.ns;
+    return rtmi_untile(&p, s->h_partial, out_linear, out_rgb8);
 }
 
 // ---- several GPUs of this process behind one handle: scene replicated, tiles t % n, one gather on devices[0] -----

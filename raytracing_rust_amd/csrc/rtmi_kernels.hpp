@@ -557,7 +557,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
 // between passes when the per-sample buffer does not hold all ns samples at once) and, on the last pass, writes
 // the texel.  A wavefront reads 1 KB contiguous per sample.
 __global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restrict__ samples, double *__restrict__ acc,
-                                                           rtmi_texel *__restrict__ out, DevParams P, int first, int last) {
+                                                           rtmi_texel *__restrict__ out, DevParams P, int first, int last,
+                                                           int partial) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= P.ntiles_local * 64u) return;
     // a traversal-pool overflow in any pass of this call invalidates its texels: poison them (rtmi_untile and
@@ -585,13 +586,18 @@ __global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restr
             sum[0] += (double)v.x; sum[1] += (double)v.y; sum[2] += (double)v.z;
         }
     }
-    if (!last) { a[0] = sum[0]; a[64] = sum[1]; a[128] = sum[2]; return; }
+    if (!last) {
+        a[0] = sum[0]; a[64] = sum[1]; a[128] = sum[2];
+        if (!partial) return; // RTMI_FLAG_PROGRESSIVE: the texel of the samples so far is written after every pass
+    }
+    // col /= ns of the samples summed so far: all of them after the last pass (tests/test.rs:71)
+    const double n_so_far = last ? (double)P.ns : (double)(P.pass_s0 + P.pass_cnt);
     rtmi_texel tx_out;
     uint32_t q[3];
     float lin[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        const double m = sum[ch] / (double)P.ns;
+        const double m = sum[ch] / n_so_far;
         lin[ch] = (float)m;
         double g = sqrt(m);
         g = (g > 0.0) ? ((g < 1.0) ? g : 1.0) : 0.0; // nalgebra::clamp(val, 0, 1); NaN -> 0
@@ -609,8 +615,9 @@ __global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restr
 }
 // end of a pass (one thread): the unit counter goes back to zero for the next pass, the pass's units are added to
 // the progress word, and after the last pass the call's overflow count joins the sticky word
-__global__ void rtmi_pass_end_kernel(unsigned int *status, unsigned int units, int last) {
+__global__ void rtmi_pass_end_kernel(unsigned int *status, unsigned int units, unsigned int pass_spp, int last) {
     status[3] += units;
+    status[4] += pass_spp;
     status[1] = 0u;
     if (last) status[2] += status[0];
 }

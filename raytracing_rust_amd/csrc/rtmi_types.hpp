@@ -103,5 +103,6 @@ struct DevParams {
 #define RTMI_EXT_TEST_OVERFLOW 4u // RTMI_FLAG_TEST_OVERFLOW
 // status words of a scene (device memory): [0] wavefronts of the CURRENT render call that overflowed their traversal
 // pool (cleared at the start of every call), [1] unit counter of the persistent wavefronts (zero between passes),
-// [2] overflows accumulated until rtmi_scene_status() reports them, [3] units of the finished passes of this call
-#define RTMI_STATUS_WORDS 4
+// [2] overflows accumulated until rtmi_scene_status() reports them, [3] units of the finished passes of this call,
+// [4] samples per pixel of the finished passes of this call (RTMI_FLAG_PROGRESSIVE: what the framebuffer holds)
+#define RTMI_STATUS_WORDS 5

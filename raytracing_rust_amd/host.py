@@ -151,6 +151,16 @@ class Scene:
                                                          rgb.ctypes.data, C.byref(st)))
         return {"linear": lin, "rgb8": rgb, "stats": _stats(st)}
 
+    def partial_image(self, nx, ny, ns):
+        """RTMI_FLAG_PROGRESSIVE: the image of the passes finished so far of the render() call running on this scene —
+        ONLY from inside that call's progress callback.  Returns (spp_done, linear, rgb8); spp_done == 0: nothing yet."""
+        p = default_params(nx, ny, ns)
+        lin = np.zeros((ny, nx, 3), np.float32)
+        rgb = np.zeros((ny, nx, 3), np.uint8)
+        spp = C.c_uint32(0)
+        self.host._check(self.host.lib.rth_partial_image(self.h, C.byref(p), lin.ctypes.data, rgb.ctypes.data, C.byref(spp)))
+        return int(spp.value), lin, rgb
+
     def upload_multi(self, devices):
         """Keeps the scene resident on a list of GPUs of this process (rtmi_multi_create): uploads once; every later
         render_resident() costs the kernels, one gather and the un-tiling.  A device may be listed more than once."""

@@ -271,6 +271,15 @@ RTH_API int rth_render_multi(void *lowered, void *cam, const rtmi_render_params 
         return RTH_OK;
     });
 }
+// RTMI_FLAG_PROGRESSIVE: the image of the passes finished so far (only from inside the progress callback of rth_render)
+RTH_API int rth_partial_image(void *lowered, const rtmi_render_params *p, float *out_linear, uint8_t *out_rgb8, uint32_t *spp_done) {
+    return guard([&] {
+        Obj *o = LOW(lowered);
+        if (!o->dev) throw std::runtime_error("scene not uploaded: call rth_upload first");
+        if (rtmi_partial_image(o->dev, p, out_linear, out_rgb8, spp_done)) throw std::runtime_error(std::string("rtmi_partial_image: ") + rtmi_last_error());
+        return RTH_OK;
+    });
+}
 // the lowered scene resident on a list of GPUs of this process (rtmi_multi_create); replaces an earlier list
 RTH_API int rth_upload_multi(void *lowered, const int *devices, uint32_t n) {
     return guard([&] {
