@@ -310,7 +310,7 @@ def main():
                          "comma-separated device list")
     ap.add_argument("--abi-multi-child", default="", help=argparse.SUPPRESS)  # internal: run only the handle leg
     ap.add_argument("--abi-multi-steps", type=int, default=3)
-    ap.add_argument("--abi-multi-timeout", type=int, default=420, help="seconds the N > 1 child may take")
+    ap.add_argument("--abi-multi-timeout", type=int, default=240, help="seconds the N > 1 child may take")
     ap.add_argument("--no-baseline-config", action="store_true",
                     help="N > 1: skip the extra strong-scaled run of BASELINE config C5 (final_scene x5000spp)")
     ap.add_argument("--launch-timeout", type=int, default=3000, help="seconds the self-launcher waits for its ranks")
