@@ -379,7 +379,7 @@ impl SceneBuilder {
 
     /// BVHNode -> rtmi_bvh_node records in preorder; leaves appended left to right, so the primitive index is the
     /// in-order rank the tie rule needs (rt_host.cpp lower_bvh).
-    fn lower_bvh(&mut self, n: &HittableDesc, depth: u32, force_moving: bool, pad: f64, unbounded_leaves: bool) -> Result<i32, LowerError> {
+    fn lower_bvh(&mut self, n: &HittableDesc, depth: u32, force_moving: bool, pad: f64, unbounded_leaves: bool, flip_all: bool) -> Result<i32, LowerError> {
         let (left, right, bbox) = match n {
             HittableDesc::Bvh { left, right, bbox } => (left, right, bbox),
             _ => unreachable!(),
@@ -403,15 +403,13 @@ impl SceneBuilder {
             let h = strip_flips(if c == 0 { left } else { right }, &mut flip);
             let (mn, mx);
             if let HittableDesc::Bvh { bbox: sub_box, .. } = &**h {
-                if flip {
-                    return Err(LowerError::Unsupported("FlipNormals around a BVHNode inside a BVH is not lowered".into()));
-                }
-                child[c] = self.lower_bvh(h, depth + 1, force_moving, pad, unbounded_leaves)?;
+                // FlipNormals around an inner BVHNode: the flip goes down to every primitive of the subtree
+                child[c] = self.lower_bvh(h, depth + 1, force_moving, pad, unbounded_leaves, flip_all != flip)?;
                 let (a, b) = put_box(sub_box);
                 mn = a;
                 mx = b;
             } else {
-                let prim = self.push_prim(h, flip, force_moving)?;
+                let prim = self.push_prim(h, flip != flip_all, force_moving)?;
                 child[c] = leaf_ref(self.out.prim_meta[prim].r#type, prim);
                 // gate = the box of THIS node, the leaf's parent in the reference tree, rounded like every node box
                 let (gmn, gmx) = put_box(bbox);
@@ -689,7 +687,7 @@ impl SceneBuilder {
                 let (prunable, _) = contained(h, scale / 65536.0);
                 it.scale = if prunable { scale as f32 } else { 1e30 }; // 1e30: the pruning margin swallows every distance
                 let prim_begin = self.out.prim_meta.len();
-                it.first = self.lower_bvh(h, 1, contains_moving(h), scale / 8192.0, !prunable)?;
+                it.first = self.lower_bvh(h, 1, contains_moving(h), scale / 8192.0, !prunable, false)?;
                 let (mut lo, mut hi) = (self.out.bvh_time_lo, self.out.bvh_time_hi);
                 moving_time_range(h, &mut lo, &mut hi);
                 self.out.bvh_time_lo = lo;

@@ -759,7 +759,7 @@ static void moving_time_range(const Hittable *h, float &lo, float &hi) {
     }
 }
 
-int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves) {
+int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves, bool flip_all) {
     if (depth > out.max_bvh_depth) out.max_bvh_depth = depth;
     const int32_t id = (int32_t)out.nodes.size();
     out.nodes.push_back(rtmi_bvh_node{});
@@ -775,12 +775,13 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
         bool flip = false;
         const Hittable *h = strip_flips(ch[c], flip);
         if (auto sub = dynamic_cast<const BVHNode *>(h)) {
-            if (flip) throw Unsupported("FlipNormals around a BVHNode inside a BVH is not lowered");
-            child[c] = lower_bvh(*sub, depth + 1, force_moving, pad, unbounded_leaves);
+            // FlipNormals around an inner BVHNode (hittable.rs:67-88 delegates and negates the normal of whatever is
+            // hit below): the flip goes down to every primitive of the subtree
+            child[c] = lower_bvh(*sub, depth + 1, force_moving, pad, unbounded_leaves, flip_all != flip);
             rtmi_bvh_node &me = out.nodes[(size_t)id];
             put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, sub->bbox_);
         } else {
-            const int prim = push_prim(*h, flip, force_moving);
+            const int prim = push_prim(*h, flip != flip_all, force_moving);
             child[c] = RTMI_LEAF(out.prim_meta[(size_t)prim].type, prim);
             { // gate = the box of THIS node, the leaf's parent in the reference tree, rounded like every node box
                 float gmn[3], gmx[3];
@@ -1010,7 +1011,7 @@ void SceneBuilder::lower_item(const Hittable &top) {
         const bool prunable = contained(*bvh, scale / 65536.0, tb, any);
         it.scale = prunable ? (float)scale : 1e30f; // 1e30: the pruning margin swallows every distance
         const size_t prim_begin = out.prim_meta.size();
-        it.first = lower_bvh(*bvh, 1, contains_moving(bvh), scale / 8192.0, !prunable);
+        it.first = lower_bvh(*bvh, 1, contains_moving(bvh), scale / 8192.0, !prunable, false);
         moving_time_range(bvh, out.bvh_time_lo, out.bvh_time_hi);
         if (prunable) { // alternative (SAH) tree over the same primitives, traversed by the cooperative kernel
             std::vector<int> prims;

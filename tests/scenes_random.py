@@ -113,6 +113,8 @@ def random_scene(api, seed, only=None, instanced=False):
                 objs.append(api.FlipNormals(p) if rng.random() < 0.1 else p)
             if n > 6 and rng.random() < 0.3:  # a BVH built earlier as one of the objects of this one
                 inner = api.BVHNode(objs[:n // 2], 0.0, 1.0)
+                if instanced and rng2.random() < 0.5:
+                    inner = api.FlipNormals(inner)  # hittable.rs:67-88 around a subtree: every normal below is negated
                 objs = [inner] + objs[n // 2:]
             world.push(_wrap(api, rng, api.BVHNode(objs, 0.0, 1.0)))
         else:  # a participating medium inside a (transformed) boundary; FlipNormals outside only
