@@ -638,9 +638,10 @@ impl SceneBuilder {
                     if medium {
                         return Err(LowerError::Unsupported("nested ConstantMedium is not lowered".into()));
                     }
-                    if it.xform_count > 0 {
-                        return Err(LowerError::Unsupported("ConstantMedium inside Traslate/Rotate is not lowered".into()));
+                    if it.xform_count > 15 {
+                        return Err(LowerError::Unsupported("ConstantMedium inside more than 15 Traslate/Rotate wrappers".into()));
                     }
+                    medium_outer = it.xform_count as u32; // the wrappers peeled so far hold the medium itself, not its boundary
                     medium = true;
                     it.medium_material = self.material_index(phase);
                     it.neg_inv_density = -(1.0f32 / (*density as f32));
@@ -659,7 +660,7 @@ impl SceneBuilder {
                 _ => break,
             }
         }
-        it.flags = (if flip { RTMI_ITEMFLAG_FLIP } else { 0 }) | (if medium { RTMI_ITEMFLAG_MEDIUM } else { 0 });
+        it.flags = (if flip { RTMI_ITEMFLAG_FLIP } else { 0 }) | (if medium { RTMI_ITEMFLAG_MEDIUM } else { 0 }) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT);
         match &**h {
             HittableDesc::Bvh { bbox, .. } => {
                 it.kind = RTMI_ITEM_BVH;

@@ -53,6 +53,8 @@ pub const RTMI_ITEM_LIST: i32 = 0;
 pub const RTMI_ITEM_BVH: i32 = 1;
 pub const RTMI_ITEMFLAG_FLIP: u32 = 1;
 pub const RTMI_ITEMFLAG_MEDIUM: u32 = 2;
+/// MEDIUM items: bits 8..11 = number of the item's first transforms that wrap the ConstantMedium itself
+pub const RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT: u32 = 8;
 pub const RTMI_NO_CHILD: i32 = 0x7fff_ffff;
 
 #[repr(C)]

@@ -142,6 +142,12 @@ typedef struct {
 enum { RTMI_ITEM_LIST = 0, RTMI_ITEM_BVH = 1 };
 #define RTMI_ITEMFLAG_FLIP 1u
 #define RTMI_ITEMFLAG_MEDIUM 2u /* ConstantMedium (src/medium.rs): geometry is the boundary */
+/* MEDIUM items: bits 8..11 = how many of the item's transforms (its FIRST ones) wrap the ConstantMedium itself instead of its
+ * boundary — Traslate(ConstantMedium(..)) / Rotate(ConstantMedium(..)), which the generic wrappers allow (traslate.rs:6-9).
+ * The boundary is still queried through the whole chain; the medium's own arithmetic (medium.rs:38-47: the norm of the
+ * ray direction, the scattering point) runs on the ray as those outer wrappers hand it down, and the point and normal go
+ * back through them (traslate.rs:21-22, rotate.rs:94-105).  0 = the medium is outside all transforms. */
+#define RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT 8
 typedef struct {
     int32_t kind;
     int32_t first;           /* LIST: first primitive | BVH: root node */

@@ -208,6 +208,8 @@ static int validate(const rtmi_scene_desc *d) {
         if ((it.flags & RTMI_ITEMFLAG_MEDIUM) &&
             (it.medium_material < 0 || (uint32_t)it.medium_material >= d->n_materials))
             return fail(RTMI_ERR_INVALID, "medium material out of range");
+        if ((int32_t)((it.flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) > it.xform_count)
+            return fail(RTMI_ERR_INVALID, "more outer medium transforms than the item has transforms");
     }
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const rtmi_material &m = d->materials[i];
@@ -260,7 +262,7 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         // so the kernel's fused two-root boundary query needs no dependent loads of the primitive's meta and planes
         std::vector<rtmi_item> items(d->items, d->items + d->n_items);
         for (rtmi_item &it : items) {
-            it.flags &= (RTMI_ITEMFLAG_FLIP | RTMI_ITEMFLAG_MEDIUM);
+            it.flags &= (RTMI_ITEMFLAG_FLIP | RTMI_ITEMFLAG_MEDIUM | (15u << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT));
             if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && it.kind == RTMI_ITEM_LIST && it.count == 1 &&
                 d->prim_meta[it.first].type == RTMI_PRIM_SPHERE) {
                 it.flags |= RTMI_ITEMFLAG_DEV_MEDIUM_SPHERE;

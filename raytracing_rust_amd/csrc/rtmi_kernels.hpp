@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                         int pf;
                         if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, stack, t1, pf, prof, slot)) {
                             if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, stack, t2, pf, prof, slot)) {
-                                if (medium_sample(t1, t2, P.t_min, closest, __builtin_sqrtf(W.a), I.neg_inv_density, g, k0, k1, tm)) {
+                                if (medium_sample(t1, t2, P.t_min, closest, medium_dir_norm(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
                                     closest = tm; best_item = (int)it; best_medium = true;
                                 }
                             }
@@ -200,8 +200,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             W.o = pa.ro; W.d = pa.rd;
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
-            float wdn = 0.0f;     // |W.d|, evaluated at the first medium of this query (wave-uniform flag) and shared by the rest
-            bool wdn_done = false;
             for (uint32_t it = 0; it < sc.n_items; it++) { // executed by all 64 lanes
                 const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
                 RayF R = W;
@@ -233,9 +231,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, P.use_alt != 0u, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
                         h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, P.use_alt != 0u, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
                     }
-                    if (!wdn_done) { wdn = __builtin_sqrtf(W.a); wdn_done = true; }
                     if (need && h1 && h2) {
-                        if (medium_sample(t1, t2, P.t_min, closest, wdn, I.neg_inv_density, g, k0, k1, tm)) {
+                        // (one square root per medium: sharing it between the media of a query measured -1.1 %,
+                        // profiles/r03_experiments/wdn_shared_norm_ab.log)
+                        if (medium_sample(t1, t2, P.t_min, closest, medium_dir_norm(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
                             closest = tm; best_item = (int)it; best_medium = true;
                         }
                     }
@@ -451,7 +450,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
                         } else {
                             if (have) {
                                 float tm;
-                                if (medium_sample(t1, bt, P.t_min, closest, __builtin_sqrtf(W.a), sc.items[it].it.neg_inv_density, g, k0, k1, tm)) {
+                                if (medium_sample(t1, bt, P.t_min, closest, medium_dir_norm(sc, iflags, sc.items[it].it.xform_first, W), sc.items[it].it.neg_inv_density, g, k0, k1, tm)) {
                                     closest = tm; best_item = it; best_medium = true;
                                 }
                             }

@@ -257,9 +257,18 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevPar
 // ConstantMedium::hit after both boundary queries — medium.rs:33-53.  Returns true when the
 // medium scatters before the boundary exit / the closest hit so far; the draw happens only when
 // the clamped interval is non-empty, as in the reference.
-// `dn` = |direction| of the WORLD ray (medium.rs:38 `ray.direction().norm()`), evaluated once per query by the caller
-// as sqrt(W.a): W.a is dot(d, d) already (ray_derive), the same expression norm() squares — same bits, and the two media
-// of final_scene share one square root per query instead of a dot product and a square root each.
+// `dn` = |direction| of the WORLD ray (medium.rs:38 `ray.direction().norm()`), passed by the caller as sqrt(W.a): W.a is
+// dot(d, d) already (ray_derive), the same expression norm() squares — same bits without a second dot product.
+// |direction| of the ray a ConstantMedium sees (medium.rs:38): the world ray's, or — for a medium that sits INSIDE the
+// first `outer` transforms of its item (rtmi.h, RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) — the ray those wrappers hand down.
+// Wave-uniform `flags`; the rare path reads the transforms from memory.
+__device__ __forceinline__ float medium_dir_norm(const DevScene &sc, uint32_t flags, int xform_first, const RayF &W) {
+    const int outer = (int)((flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u);
+    if (outer == 0) return __builtin_sqrtf(W.a); // W.a is dot(d, d): the expression norm() squares
+    F3 o = W.o, d = W.d;
+    if (!xform_ray(sc.xforms, xform_first, outer, o, d)) return __builtin_sqrtf(W.a); // translations only: same direction
+    return norm(d);
+}
 template <typename RngT>
 __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, float dn,
                                               float neg_inv_density, RngT &g, uint32_t k0, uint32_t k1, float &t_out) {
@@ -308,6 +317,13 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
             rec_mat = rec[1]; rec_t0 = rec[2]; rec_t1 = rec[3];
             hp = pa.ro + pa.rd * closest;      // ray.pointing_at(t) — medium.rs:47
             hn = f3(1.0f, 0.0f, 0.0f);         // medium.rs:48
+            const int outer = (int)((iflags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u);
+            if (outer > 0) { // the medium sits inside `outer` wrappers: its point is taken on THEIR ray and handed back
+                F3 lo = pa.ro, ld = pa.rd;
+                xform_ray(sc.xforms, xform_first, outer, lo, ld);
+                hp = lo + ld * closest;
+                xform_hit(sc.xforms, xform_first, outer, hp, hn);
+            }
         } else {
             const int idx = best_pf >> 3, face = best_pf & 7;
             const float4 *rec = sc.shade_prim + (size_t)idx * 4;

@@ -962,12 +962,14 @@ void SceneBuilder::lower_item(const Hittable &top) {
     it.alt_first = -1;
     it.xform_first = (int32_t)out.xforms.size();
     bool flip = false, medium = false;
+    uint32_t medium_outer = 0;
     const Hittable *h = &top;
     for (;;) { // peel wrappers, outermost first
         if (auto f = dynamic_cast<const FlipNormals *>(h)) { flip = !flip; h = f->inner().get(); continue; }
         if (auto m = dynamic_cast<const ConstantMedium *>(h)) {
             if (medium) throw Unsupported("nested ConstantMedium is not lowered");
-            if (it.xform_count > 0) throw Unsupported("ConstantMedium inside Traslate/Rotate is not lowered");
+            if (it.xform_count > 15) throw Unsupported("ConstantMedium inside more than 15 Traslate/Rotate wrappers");
+            medium_outer = (uint32_t)it.xform_count; // the wrappers peeled so far hold the medium itself, not its boundary
             medium = true;
             it.medium_material = material_index(m->phase_function_.get());
             it.neg_inv_density = -(1.0f / (float)m->density_);
@@ -990,7 +992,7 @@ void SceneBuilder::lower_item(const Hittable &top) {
         }
         break;
     }
-    it.flags = (flip ? RTMI_ITEMFLAG_FLIP : 0u) | (medium ? RTMI_ITEMFLAG_MEDIUM : 0u);
+    it.flags = (flip ? RTMI_ITEMFLAG_FLIP : 0u) | (medium ? RTMI_ITEMFLAG_MEDIUM : 0u) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT);
     if (auto bvh = dynamic_cast<const BVHNode *>(h)) {
         it.kind = RTMI_ITEM_BVH;
         put_box(it.root_min, it.root_max, bvh->bbox_);
