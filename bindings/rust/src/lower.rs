@@ -626,6 +626,7 @@ impl SceneBuilder {
         let mut it = zero_item();
         it.xform_first = self.out.xforms.len() as i32;
         let (mut flip, mut medium) = (false, false);
+        let mut medium_outer = 0u32;
         let mut h = top;
         loop {
             // peel wrappers, outermost first

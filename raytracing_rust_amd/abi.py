@@ -10,6 +10,7 @@ import os
 from . import build as _build
 
 RTMI_ABI_VERSION = 6
+RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT = 8  # MEDIUM items: how many of the first transforms wrap the medium itself (bits 8..11)
 RTMI_PRIMFLAG_XF_COUNT_SHIFT = 4   # instanced primitive: number of its own transforms (bits 4..7)
 RTMI_PRIMFLAG_XF_FIRST_SHIFT = 12  # ... and the index of the first one in xforms (bits 12..31)
 RTMI_MAX_BVH_DEPTH = 24

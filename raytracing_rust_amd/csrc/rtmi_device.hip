@@ -353,6 +353,9 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     s->dev.has_prim_xf = 0u;
     for (uint32_t i = 0; i < d->n_prims; i++)
         if ((d->prim_meta[i].flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) s->dev.has_prim_xf = 1u;
+    s->dev.has_medium_outer = 0u;
+    for (uint32_t i = 0; i < d->n_items; i++)
+        if ((d->items[i].flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) s->dev.has_medium_outer = 1u;
     if (hipMalloc(reinterpret_cast<void **>(&s->status), RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess ||
         hipMemset(s->status, 0, RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess) {
         rtmi_scene_destroy(s);
@@ -583,7 +586,8 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
     // persistent grid: as many wavefronts as the kernel instantiation keeps resident (4 SIMDs x its waves per SIMD)
     const uint32_t wps_req = (p->flags >> 8) & 7u; // experiment knob: requested waves per SIMD (0 = default)
-    const uint32_t wps_run = (coop && !prof && !sigf && !s->dev.has_prim_xf && (wps_req == 3u || wps_req == 5u)) ? wps_req : (coop && prof ? 3u : 4u);
+    const bool inst = s->dev.has_prim_xf != 0u || s->dev.has_medium_outer != 0u; // the rare compositions: own instantiations
+    const uint32_t wps_run = (coop && !prof && !sigf && !inst && (wps_req == 3u || wps_req == 5u)) ? wps_req : (coop && prof ? 3u : 4u);
     const uint64_t run_slots = (uint64_t)(s->slots / 20) * 4u * wps_run;
     if (coop) {
         const size_t spill_bytes = (size_t)s->slots * P.spill_cap * sizeof(uint2);
@@ -619,8 +623,8 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     } while (0)
     if (coop) {
         const uint32_t wps = wps_req;
-        if (s->dev.has_prim_xf) { // scenes with instanced primitives: their own instantiations (no diagnostics builds)
-            if (prof) return fail(RTMI_ERR_UNSUPPORTED, "the profiling build has no instantiation for instanced primitives");
+        if (inst) { // instanced primitives, media inside transforms: their own instantiations (no diagnostics builds)
+            if (prof) return fail(RTMI_ERR_UNSUPPORTED, "the profiling build has no instantiation for instanced primitives / media inside transforms");
             if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, true);
             else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, true);
             else RTMI_LAUNCH_COOP(false, false, 4, false, true);

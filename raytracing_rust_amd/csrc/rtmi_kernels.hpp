@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     if (need && h1 && h2) {
                         // (one square root per medium: sharing it between the media of a query measured -1.1 %,
                         // profiles/r03_experiments/wdn_shared_norm_ab.log)
-                        if (medium_sample(t1, t2, P.t_min, closest, medium_dir_norm(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
+                        if (medium_sample(t1, t2, P.t_min, closest, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
                             closest = tm; best_item = (int)it; best_medium = true;
                         }
                     }

@@ -261,8 +261,12 @@ __device__ __forceinline__ void camera_sample(const DevCamera &cam, const DevPar
 // dot(d, d) already (ray_derive), the same expression norm() squares — same bits without a second dot product.
 // |direction| of the ray a ConstantMedium sees (medium.rs:38): the world ray's, or — for a medium that sits INSIDE the
 // first `outer` transforms of its item (rtmi.h, RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) — the ray those wrappers hand down.
-// Wave-uniform `flags`; the rare path reads the transforms from memory.
+// Wave-uniform `flags`; the rare path reads the transforms from memory.  INST = false: the instantiation for scenes
+// without such media (and without instanced primitives) carries none of this — merely present, the rare path cost
+// final_scene 1.7 % (profiles/r03_experiments/medium_outer_ab.log).
+template <bool INST = true>
 __device__ __forceinline__ float medium_dir_norm(const DevScene &sc, uint32_t flags, int xform_first, const RayF &W) {
+    if (!INST) return __builtin_sqrtf(W.a);
     const int outer = (int)((flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u);
     if (outer == 0) return __builtin_sqrtf(W.a); // W.a is dot(d, d): the expression norm() squares
     F3 o = W.o, d = W.d;
@@ -317,7 +321,7 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
             rec_mat = rec[1]; rec_t0 = rec[2]; rec_t1 = rec[3];
             hp = pa.ro + pa.rd * closest;      // ray.pointing_at(t) — medium.rs:47
             hn = f3(1.0f, 0.0f, 0.0f);         // medium.rs:48
-            const int outer = (int)((iflags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u);
+            const int outer = INST ? (int)((iflags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) : 0;
             if (outer > 0) { // the medium sits inside `outer` wrappers: its point is taken on THEIR ray and handed back
                 F3 lo = pa.ro, ld = pa.rd;
                 xform_ray(sc.xforms, xform_first, outer, lo, ld);

@@ -67,6 +67,7 @@ struct DevScene {
     const uint8_t *image_data;
     uint32_t n_items;
     uint32_t has_prim_xf; // some primitive carries its own transform chain (instanced primitive, rtmi.h)
+    uint32_t has_medium_outer; // some medium sits inside transforms of its item (RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT)
 };
 
 struct DevCamera {

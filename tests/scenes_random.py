@@ -122,6 +122,8 @@ def random_scene(api, seed, only=None, instanced=False):
                 else api.Cube(rng.uniform(-2.5, 0, 3), rng.uniform(0.5, 2.5, 3), api.Dielectric(1.5))
             b = _wrap(api, rng, b, allow_flip=False)
             med = api.ConstantMedium(b, float(rng.choice([0.0, 0.01, 0.2, 1.0, 5.0])), _texture(api, rng))
+            if instanced and rng2.random() < 0.5:
+                med = _wrap(api, rng2, med)  # Traslate / Rotate / FlipNormals AROUND the medium (traslate.rs:6-9 is generic)
             world.push(api.FlipNormals(med) if rng.random() < 0.1 else med)
     return real
 

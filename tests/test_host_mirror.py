@@ -98,8 +98,10 @@ def test_unsupported_nesting_fails_loudly(host):
     mat = host.Lambertian(host.SolidTexture(1, 1, 1))
     tex = host.SolidTexture(1, 1, 1)
     inner = host.ConstantMedium(host.Sphere((0, 0, 0), 1.0, mat), 0.1, tex)
+    a = host.lower(host.Rotate(host.AXIS_Y, host.Traslate(inner, (1, 0, 0)), 20.0)).arrays()  # a medium INSIDE two transforms lowers since r03
+    assert (a["items"][0].flags >> abi.RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15 == 2 and a["items"][0].xform_count == 2
     with pytest.raises(Unsupported):
-        host.lower(host.Traslate(inner, (1, 0, 0)))  # medium inside a transform
+        host.lower(host.ConstantMedium(inner, 0.2, tex))  # nested media
     # (an instanced PRIMITIVE as a BVH leaf lowers since r03: tests/test_random_scenes.py)
     sub = host.BVHNode([host.Sphere((0, 0, 0), 1.0, mat), host.Sphere((0, 2, 0), 1.0, mat)], 0.0, 1.0)
     nested = host.BVHNode([host.Traslate(sub, (1, 0, 0)), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0)
