@@ -216,6 +216,8 @@ typedef struct {
 #define RTMI_FLAG_SYNC 8u      /* per-lane BVH traversal instead of the wave-cooperative one (exact mode always is) */
 #define RTMI_FLAG_ASYNC 16u    /* per-lane state-machine kernel (experimental, kept for comparison) */
 #define RTMI_FLAG_REF_TREE 64u /* cooperative kernel: walk the reference-topology tree, not the alternative one */
+#define RTMI_FLAG_BLOCK_COOP 32768u /* experimental: the four wavefronts of a workgroup share one traversal stack
+                                * (csrc/rtmi_bvh_block.hpp); scenes whose BVH items all carry alternative trees, else ignored */
 /* Diagnostic knobs in the upper flag bits (results never depend on them): bits 8..10 = wavefronts per SIMD the
  * cooperative kernel is compiled for (3 or 5; default 4); bit 11 = a 256-entry LDS part of the traversal stack,
  * so that it spills to global memory all the time (tests/test_gpu_parity.py). */
@@ -281,8 +283,10 @@ typedef struct {
     double kernel_ms;  /* render + resolve kernels, from HIP events on the launch stream */
     double render_ms;  /* the render kernel alone */
     uint64_t samples;  /* camera paths traced by this call */
-    uint32_t tiles, chunks, blocks, reserved;
+    uint32_t tiles, chunks, blocks;
+    uint32_t kernel;   /* which render kernel ran (diagnostics; results never depend on it): RTMI_KERNEL_* */
 } rtmi_stats;
+enum { RTMI_KERNEL_PERLANE = 0, RTMI_KERNEL_WAVE_COOP = 1, RTMI_KERNEL_ASYNC = 2, RTMI_KERNEL_BLOCK_COOP = 3 };
 
 typedef struct rtmi_scene rtmi_scene;
 

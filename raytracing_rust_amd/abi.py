@@ -22,6 +22,8 @@ RTMI_FLAG_SYNC = 8
 RTMI_FLAG_ASYNC = 16
 RTMI_FLAG_SKY = 32
 RTMI_FLAG_REF_TREE = 64
+RTMI_FLAG_BLOCK_COOP = 32768
+RTMI_KERNEL_PERLANE, RTMI_KERNEL_WAVE_COOP, RTMI_KERNEL_ASYNC, RTMI_KERNEL_BLOCK_COOP = 0, 1, 2, 3
 RTMI_FLAG_FACE_FORWARD = 128
 RTMI_FLAG_UV_BOOK = 4096
 RTMI_FLAG_TEST_OVERFLOW = 8192
@@ -119,7 +121,7 @@ class Texel(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("render_ms", C.c_double), ("samples", C.c_uint64),
-                ("tiles", C.c_uint32), ("chunks", C.c_uint32), ("blocks", C.c_uint32), ("reserved", C.c_uint32)]
+                ("tiles", C.c_uint32), ("chunks", C.c_uint32), ("blocks", C.c_uint32), ("kernel", C.c_uint32)]
 
 
 # every entry point include/rtmi.h declares (tests check that the library exports them all)

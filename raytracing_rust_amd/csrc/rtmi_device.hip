@@ -63,6 +63,7 @@ struct rtmi_scene {
     unsigned int *status = nullptr; // RTMI_STATUS_WORDS device words, see rtmi_types.hpp
     int slots = 0;                  // CUs x 16: resident wavefronts the render kernels are launched with
     bool has_alt = false;           // some BVH item carries an alternative tree
+    bool all_alt = false;           // every BVH item does (and there is one): the workgroup-cooperative kernel can run
     // scratch of the blocking host API (grow-only, so a host that renders frame after frame allocates once)
     rtmi_texel *texels = nullptr;
     size_t texel_count = 0;
@@ -349,6 +350,9 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
     s->dev.nodes = nodes4;
     for (uint32_t i = 0; i < d->n_items; i++)
         if (d->items[i].kind == RTMI_ITEM_BVH && d->items[i].alt_first >= 0) s->has_alt = true;
+    s->all_alt = s->has_alt;
+    for (uint32_t i = 0; i < d->n_items; i++)
+        if (d->items[i].kind == RTMI_ITEM_BVH && d->items[i].alt_first < 0) s->all_alt = false;
     s->dev.n_items = d->n_items;
     s->dev.has_prim_xf = 0u;
     for (uint32_t i = 0; i < d->n_prims; i++)
@@ -582,6 +586,9 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
 #ifndef RTMI_COOP_CAP
 #define RTMI_COOP_CAP 512u
 #endif
+#ifndef RTMI_BLK_CAP /* entries of the workgroup's shared stack: 40 000 B of LDS per workgroup, four workgroups per CU */
+#define RTMI_BLK_CAP 2432u
+#endif
     P.coop_cap = ext ? RTMI_COOP_CAP : P.spill_cap;
     if (p->flags & (1u << 11)) P.coop_cap = 256u; // test knob: a pool this small spills all the time
     // persistent grid: as many wavefronts as the kernel instantiation keeps resident (4 SIMDs x its waves per SIMD)
@@ -598,6 +605,12 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
         }
     }
     P.spill = s->spill;
+    // workgroup-cooperative traversal (rtmi_bvh_block.hpp): alternative trees only, no diagnostics build
+    const bool bcoop = coop && (p->flags & RTMI_FLAG_BLOCK_COOP) != 0u && P.use_alt != 0u && s->all_alt && !prof && !inst &&
+                       wps_req == 0u;
+    const size_t bcoop_lds = (size_t)RTMI_BLK_LDS_WORDS(RTMI_BLK_CAP) * sizeof(uint32_t);
+    // (test knob bit 11: a stack so small that rounds are throttled all the time — room for 64 visits when it is full)
+    if (bcoop) P.coop_cap = (p->flags & (1u << 11)) ? 3u * RTMI_BLK_THREADS + 64u : RTMI_BLK_CAP;
     const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + (ext ? 0u : RTMI_RNG_RING_WORDS)) * sizeof(uint32_t);
     const uint32_t ntex = P.ntiles_local * 64u;
     uint32_t blocks_total = 0, chunks_total = 0;
@@ -608,8 +621,11 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     const uint64_t nitems = (uint64_t)P.ntiles_local * P.nchunks;
     if (nitems > 0x7fffffffull) return fail(RTMI_ERR_UNSUPPORTED, "too many (tile, chunk) items in one pass");
     // two-phase kernels: persistent wavefronts that take units from the queue; async kernel: one block per unit
+    // (workgroup-cooperative kernel: resident workgroups of RTMI_BLK_WAVES wavefronts; every wavefront takes units)
+    const uint64_t blk_slots = run_slots / RTMI_BLK_WAVES;
     const uint64_t nblocks = async ? (nitems + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK
-                                   : (nitems < run_slots ? nitems : run_slots);
+                             : bcoop ? (nitems < blk_slots ? nitems : blk_slots)
+                                     : (nitems < run_slots ? nitems : run_slots);
     const dim3 grid((uint32_t)nblocks);
     blocks_total += grid.x; chunks_total += P.nchunks;
     s->units_total += nitems;
@@ -621,7 +637,11 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds));                     \
         hipLaunchKernelGGL((rtmi_render_coop<S, PR, W, E, I>), grid, block, coop_lds, stream, s->dev, C, P);             \
     } while (0)
-    if (coop) {
+    if (bcoop) {
+        const dim3 blk(RTMI_BLK_THREADS);
+        if (sigf) hipLaunchKernelGGL((rtmi_render_bcoop<true, false>), grid, blk, bcoop_lds, stream, s->dev, C, P);
+        else hipLaunchKernelGGL((rtmi_render_bcoop<false, false>), grid, blk, bcoop_lds, stream, s->dev, C, P);
+    } else if (coop) {
         const uint32_t wps = wps_req;
         if (inst) { // instanced primitives, media inside transforms: their own instantiations (no diagnostics builds)
             if (prof) return fail(RTMI_ERR_UNSUPPORTED, "the profiling build has no instantiation for instanced primitives / media inside transforms");
@@ -678,7 +698,8 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
             pix += (uint64_t)w * h;
         }
         stats->samples = pix * p->ns;
-        stats->tiles = P.ntiles_local; stats->chunks = chunks_total; stats->blocks = blocks_total; stats->reserved = 0;
+        stats->tiles = P.ntiles_local; stats->chunks = chunks_total; stats->blocks = blocks_total;
+        stats->kernel = bcoop ? RTMI_KERNEL_BLOCK_COOP : coop ? RTMI_KERNEL_WAVE_COOP : async ? RTMI_KERNEL_ASYNC : RTMI_KERNEL_PERLANE;
         unsigned int st = 0; // this call's overflow word (the kernels have finished: ev[2] was waited for)
         HIP_TRY(hipMemcpy(&st, s->status, sizeof(st), hipMemcpyDeviceToHost));
         if (st != 0) {
@@ -818,7 +839,7 @@ static void fill_stats(rtmi_scene *s, const rtmi_render_params *p, rtmi_stats *s
         pix += (uint64_t)w * h;
     }
     stats->samples = pix * p->ns;
-    stats->tiles = nl; stats->chunks = 0; stats->blocks = 0; stats->reserved = 0;
+    stats->tiles = nl; stats->chunks = 0; stats->blocks = 0; stats->kernel = 0;
     (void)s;
 }
 

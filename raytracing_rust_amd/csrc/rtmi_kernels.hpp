@@ -3,6 +3,7 @@
 // kernel instantiation inlines the whole path); arithmetic contract as stated there.
 #pragma once
 #include "rtmi_bvh_coop.hpp"
+#include "rtmi_bvh_block.hpp"
 #include "rtmi_shade.hpp"
 
 // ----------------------------------------------------------------------------------
@@ -281,6 +282,123 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             else atomicAdd(P.prof + threadIdx.x, prof_lds[threadIdx.x]);
         }
     }
+}
+
+// ----------------------------------------------------------------------------------
+// render kernel, two-phase form with WORKGROUP-cooperative BVH traversal (rtmi_bvh_block.hpp).
+// Same per-lane program as rtmi_render_coop (items in list order, media draws in order: same bits); what changes is
+// who decides: the phase switches and the end of the kernel are votes of the whole workgroup, so that its wavefronts
+// reach every traversal call together.  A wavefront whose lanes are all done keeps voting and keeps serving as
+// workers in the shared traversal until the workgroup is done.
+// ----------------------------------------------------------------------------------
+template <bool SIG, bool INST>
+__global__ __launch_bounds__(RTMI_BLK_THREADS, 4) void rtmi_render_bcoop(DevScene sc, DevCamera cam, DevParams P) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+    const int lane = threadIdx.x & 63;
+    BlockWork bw;
+    block_work_init(bw, lds_dyn, (int)P.coop_cap);
+    float *scratch = reinterpret_cast<float *>(block_wave_scratch(bw));
+    unsigned long long sig = 0ull;
+    WaveWork w;
+    w.ltile = 0u; w.ps_base = 0u; w.obase = 0u; w.x0 = 0u; w.y0 = 0u; w.cols = 0u; w.n_valid = 0u; w.next = 0u; w.total = 0u;
+    bool queue_empty = false;
+    const uint32_t k0 = P.key0, k1 = P.key1;
+    const uint32_t threshold = P.shade_threshold * RTMI_BLK_WAVES;
+
+    uint32_t oidx = 0u, ltile = 0u;
+    bool alive = false, done = false, have_hit = false, overflow = false;
+    RngReg g;
+    rng_init(g, 0, 0);
+    Path pa;
+    pa.ro = f3(0, 0, 0); pa.rd = f3(0, 0, 1); pa.rtime = 0.0f; pa.T = f3(1, 1, 1); pa.L = f3(0, 0, 0); pa.depth = 0;
+    float closest = RTMI_FLT_MAX;
+    int best_item = -1, best_pf = 0;
+    bool best_medium = false;
+
+    for (;;) {
+        // ================= phase A =================
+        uint32_t n_hit;
+        for (;;) {
+            // one vote: lanes that still trace (low half) and lanes that hold a hit (high half)
+            const uint32_t v = block_vote(bw, (uint32_t)__popcll(__ballot(!have_hit && !done)) | ((uint32_t)__popcll(__ballot(have_hit)) << 16));
+            n_hit = v >> 16;
+            if ((v & 0xffffu) == 0u || n_hit >= threshold) break;
+            { // lanes whose path ended take the next (sample, pixel) item of the chunk (per wavefront, as in rtmi_render_coop)
+                const bool want = !have_hit && !done && !alive;
+                if (__ballot(want) != 0ull) {
+                    uint32_t smp = 0u, px = 0u, j = 0u;
+                    if (work_take(w, queue_empty, want, P, oidx, ltile, smp, px, j)) {
+                        camera_sample(cam, P, g, k0, k1, smp, j * P.nx + px, px, j, pa);
+                        alive = true;
+                    } else if (want) {
+                        done = true;
+                    }
+                }
+            }
+            const bool need = !have_hit && !done;
+            RayF W;
+            W.o = pa.ro; W.d = pa.rd;
+            ray_derive(W);
+            if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
+            for (uint32_t it = 0; it < sc.n_items; it++) { // executed by all threads of the workgroup
+                const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
+                RayF R = W;
+                if (I.xform_count > 0) {
+                    struct XPair { rtmi_xform x0, x1; };
+                    const XPair XP = RTMI_UNIFORM_LOAD(XPair, reinterpret_cast<const XPair *>(&sc.items[it].x0));
+                    if (xform_ray_item<true>(sc.xforms, I.xform_first, I.xform_count, XP.x0, XP.x1, R.o, R.d)) ray_derive(R);
+                }
+                if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
+                    float t;
+                    int pf;
+                    if (geom_query_block<INST>(sc, I, need, R, pa.rtime, P.t_min, closest, bw, t, pf, overflow)) {
+                        closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
+                    }
+                } else { // ConstantMedium::hit — medium.rs:28-56
+                    float t1 = 0.0f, t2 = 0.0f, tm;
+                    int pf;
+                    bool h1, h2;
+                    if (I.flags & RTMI_ITEMFLAG_DEV_MEDIUM_SPHERE) {
+                        h1 = false; h2 = false;
+                        if (need) sphere_two_queries(R, make_float4(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0]), h1, t1, h2, t2);
+                    } else {
+                        h1 = geom_query_block<INST>(sc, I, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, bw, t1, pf, overflow);
+                        h2 = geom_query_block<INST>(sc, I, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, bw, t2, pf, overflow);
+                    }
+                    if (need && h1 && h2) {
+                        if (medium_sample(t1, t2, P.t_min, closest, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
+                            closest = tm; best_item = (int)it; best_medium = true;
+                        }
+                    }
+                }
+            }
+            if (need) {
+                if (best_item >= 0) {
+                    have_hit = true;
+                } else { // miss: black background (color.rs:21)
+                    if (P.sky) pa.L = pa.L + pa.T * sky_color(pa.rd);
+                    path_end(P, oidx, pa);
+                    if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
+                    alive = false;
+                }
+            }
+        }
+        // ================= phase B =================
+        if (n_hit == 0u) break; // nobody traces, nobody holds a hit: the workgroup is done
+        {
+            const bool shading = have_hit;
+            have_hit = false;
+            if (SIG && shading) sig += (unsigned long long)sig_mix(__float_as_uint(closest), pa.depth);
+            const bool goes_on = shade_hit<RngReg, INST>(sc, P.max_depth, P.ext, g, k0, k1, shading, closest, best_item, best_pf, best_medium, pa, scratch);
+            if (shading && !goes_on) {
+                path_end(P, oidx, pa);
+                if (SIG) { atomicAdd(P.path_sig + (size_t)ltile * 64 + (oidx & 63u), sig); sig = 0ull; }
+                alive = false;
+            }
+        }
+    }
+    if (P.ext & RTMI_EXT_TEST_OVERFLOW) overflow = true; // test knob: exercise the error path
+    if (__ballot(overflow) != 0ull && lane == 0) atomicAdd(P.status, 1u); // reported loudly by the host
 }
 
 // ----------------------------------------------------------------------------------

@@ -210,7 +210,7 @@ class Scene:
 
 def _stats(st):
     return {"kernel_ms": st.kernel_ms, "render_ms": st.render_ms, "samples": int(st.samples), "tiles": st.tiles,
-            "chunks": st.chunks, "blocks": st.blocks}
+            "chunks": st.chunks, "blocks": st.blocks, "kernel": st.kernel}
 
 
 class _Camera(_Obj):

@@ -32,9 +32,10 @@ CASES = [
 
 
 @pytest.mark.parametrize("flags", [0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_REF_TREE,
+                                   abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_BLOCK_COOP,
                                    abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL,
                                    abi.RTMI_FLAG_ASYNC, abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL],
-                         ids=["exact", "coop-fast", "coop-fast-reftree", "perlane-fast", "async-exact", "async-fast"])
+                         ids=["exact", "coop-fast", "coop-fast-reftree", "blockcoop-fast", "perlane-fast", "async-exact", "async-fast"])
 @pytest.mark.parametrize("name,nx,ny,ns", CASES)
 def test_scene_matches_fp32_oracle(host, orc32, name, nx, ny, ns, flags):
     cam, world = scenes_extra.build(host, name, nx, ny, seed=1)
@@ -78,9 +79,12 @@ def test_fast_cull_equals_exact(host, name, nx, ny, ns):
     for label, flags in (("perlane-fast", abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL),
                          ("coop-fast", abi.RTMI_FLAG_FAST_CULL),
                          ("coop-fast-reftree", abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_REF_TREE),
+                         ("blockcoop-fast", abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_BLOCK_COOP),
                          ("async-fast", abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL)):
         b = sc.render(cam, nx, ny, ns, seed=42, flags=flags, sig=True)
         print(", %s %.1f ms" % (label, b["stats"]["render_ms"]), end="")
+        if label == "blockcoop-fast":  # these four scenes qualify (every BVH item has an alternative tree): it really ran
+            assert b["stats"]["kernel"] == abi.RTMI_KERNEL_BLOCK_COOP
         assert np.array_equal(a["sig"], b["sig"]), label
         assert np.array_equal(a["linear"], b["linear"]), label
         assert np.array_equal(a["rgb8"], b["rgb8"]), label
@@ -154,7 +158,10 @@ def test_traversal_stack_spill_to_global_memory(host, name, nx, ny, ns):
     cam, world = scenes_extra.build(host, name, nx, ny, seed=1)
     sc = host.lower(world)
     exact = sc.render(cam, nx, ny, ns, seed=42, flags=0, sig=True)
-    for flags in (abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | (1 << 11)):
+    # (the workgroup-cooperative kernel has no spill: with the knob its stack holds 832 entries and every round that
+    # finds more than 64 pending is throttled to the visits whose pushes still fit)
+    for flags in (abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | (1 << 11),
+                  abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_BLOCK_COOP | (1 << 11)):
         got = sc.render(cam, nx, ny, ns, seed=42, flags=flags, sig=True)
         assert np.array_equal(exact["sig"], got["sig"]), flags
         assert np.array_equal(exact["linear"], got["linear"]), flags

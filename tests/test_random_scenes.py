@@ -49,6 +49,7 @@ def test_device_equals_fp32_oracle_on_random_scenes(host, orc32, seed, instanced
     dsky = abi.RTMI_FLAG_SKY if sky else 0
     for label, flags in (("exact", 0), ("coop-fast", abi.RTMI_FLAG_FAST_CULL),
                          ("coop-fast-reftree", abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_REF_TREE),
+                         ("blockcoop-fast", abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_BLOCK_COOP),  # ignored where it cannot run
                          ("perlane-fast", abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL),
                          ("async-fast", abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL)):
         got = sc.render(cam, nx, ny, ns, seed=42, flags=flags | dsky, sig=True)
