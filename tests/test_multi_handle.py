@@ -186,3 +186,28 @@ def test_render_device_on_two_streams_of_one_handle_serialises_on_the_device(hos
     for k, s in enumerate((42, 43)):
         lin, rgb = rdist.untile(params[k], bufs[k].cpu().numpy()[None])
         assert np.array_equal(lin, want[s]["linear"]) and np.array_equal(rgb, want[s]["rgb8"])
+
+
+@pytest.mark.gpu
+def test_c5_x5000_as_eight_ranks_through_the_multi_handle(host):
+    """BASELINE config C5 — final_scene 1920x1080x5000 spp tile-split over 8 GPUs — at FULL size through the C ABI's
+    persistent handle, all eight ranks on this one GPU (rtmi_multi_create with the same device eight times: eight
+    resident scenes, eight 20.7-GB per-sample buffers = 166 GB of the 288, eight streams, the gather into one
+    framebuffer and the 8-way un-tiling): the image equals rtmi_render's of the whole frame bit for bit.  The lit
+    variant of the scene (light rect the right way round) so that the radiance carries information; 10.4 G paths each
+    way.  What this leaves unmeasured of the 8-GPU config: the RCCL gather between DISTINCT devices."""
+    nx, ny, ns = 1920, 1080, 5000
+    cam, world = scenes_extra.build(host, "lit_final_scene", nx, ny, seed=1)
+    sc = host.lower(world)
+    sc.upload_multi([0] * 8)
+    try:
+        res = sc.render_resident(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+        assert res["stats"]["samples"] == nx * ny * ns
+        print("8 ranks on one GPU: %.0f ms" % res["stats"]["kernel_ms"])
+    finally:
+        sc.free_multi()
+    sc.upload(0)
+    one = sc.render(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)  # passes within the default 48-GiB budget
+    print("1 rank: %.0f ms, mean radiance %.4f" % (one["stats"]["kernel_ms"], float(one["linear"].mean())))
+    assert float(one["linear"].mean()) > 0.01
+    assert np.array_equal(res["linear"], one["linear"]) and np.array_equal(res["rgb8"], one["rgb8"])
