@@ -47,7 +47,8 @@ enum { RTMI_TEX_SOLID = 0, RTMI_TEX_CHECKER = 1, RTMI_TEX_NOISE = 2, RTMI_TEX_IM
 typedef struct {
     int32_t kind;
     int32_t i0; /* CHECKER: odd texture index | NOISE: perlin table index | IMAGE: image index */
-    int32_t i1; /* CHECKER: even texture index */
+    int32_t i1; /* CHECKER: even texture index.  Checkers may nest (texture.rs:28-48 is generic over its children) up to
+                 * 16 levels; a deeper nest or a checker that reaches itself is RTMI_ERR_INVALID at rtmi_scene_create */
     int32_t pad;
     float f0, f1, f2; /* SOLID: r,g,b | NOISE: f0 = scale */
     float f3;

@@ -235,6 +235,18 @@ static int validate(const rtmi_scene_desc *d) {
         default: return fail(RTMI_ERR_INVALID, "bad texture kind");
         }
     }
+    { // checkers nest (texture.rs:28-48 is generic over its children); the device follows at most 16 levels, and a checker
+      // that reaches itself would never end: longest checker chain below every texture, by 17 rounds of relaxation
+        std::vector<uint8_t> depth(d->n_textures, 0);
+        for (int round = 0; round <= 16; round++)
+            for (uint32_t i = 0; i < d->n_textures; i++) {
+                const rtmi_texture &t = d->textures[i];
+                if (t.kind != RTMI_TEX_CHECKER) continue;
+                const uint8_t below = depth[t.i0] > depth[t.i1] ? depth[t.i0] : depth[t.i1];
+                depth[i] = (uint8_t)(below + 1);
+                if (depth[i] > 16) return fail(RTMI_ERR_INVALID, "checker textures nested deeper than 16 levels, or a checker that reaches itself");
+            }
+    }
     for (uint32_t i = 0; i < d->n_images; i++) {
         const rtmi_image &im = d->images[i];
         if (im.nx == 0 || im.ny == 0 || im.offset + 3ull * im.nx * im.ny > d->image_bytes)
