@@ -13,6 +13,7 @@ pub const RTMI_FLAG_ASYNC: u32 = 16;
 pub const RTMI_FLAG_SKY: u32 = 32;
 pub const RTMI_FLAG_REF_TREE: u32 = 64;
 pub const RTMI_FLAG_BLOCK_COOP: u32 = 32768;
+pub const RTMI_SAMPLE_SLOT_BYTES: u32 = 12;
 pub const RTMI_FLAG_FACE_FORWARD: u32 = 128;
 pub const RTMI_FLAG_UV_BOOK: u32 = 4096;
 /// opt-in: after every pass the framebuffer holds the image of the samples so far (rtmi_partial_image)

@@ -39,6 +39,8 @@ extern "C" {
 #define RTMI_ABI_VERSION 6u /* the scene description (6: instanced primitives, rtmi_prim_meta.flags bits 4..7, 12..31) */
 #define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
 #define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
+#define RTMI_SAMPLE_SLOT_BYTES 12u /* per-sample radiance buffer: three fp32 per finished path (budget arithmetic of
+                                   * rtmi_render_params.sample_buffer_bytes) */
 
 enum { RTMI_OK = 0, RTMI_ERR_INVALID = 1, RTMI_ERR_UNSUPPORTED = 2, RTMI_ERR_DEVICE = 3, RTMI_ERR_NOMEM = 4, RTMI_ERR_CANCELLED = 5 };
 
@@ -237,7 +239,7 @@ typedef struct {
                                 * holds the image of the samples rendered so far — their mean in sample order, quantised like
                                 * the final image, i.e. exactly the image of a render with ns = samples so far — instead of only
                                 * after the last one.  A render runs in passes when sample_buffer_bytes is smaller than
-                                * 16 B x pixels x ns (a budget of K samples' worth gives passes of K samples).  With a progress
+                                * RTMI_SAMPLE_SLOT_BYTES x pixels x ns (a budget of K samples' worth gives passes of K samples).  With a progress
                                 * callback on rtmi_render, rtmi_partial_image() fetches that image from inside the callback. */
 #define RTMI_FLAG_TEST_OVERFLOW 8192u /* test knob: the cooperative kernel reports a traversal-pool overflow although
                                 * none happened, to exercise the error path (results of that call are poisoned) */
@@ -252,8 +254,8 @@ typedef struct {
     uint32_t shade_threshold;       /* two-phase kernel: lanes holding a hit before shading starts (0 = default 40) */
     uint64_t path_sig;              /* RTMI_FLAG_PATH_SIG: DEVICE address of rtmi_local_tiles()*64 uint64 (else 0) */
     uint64_t prof;                  /* RTMI_FLAG_PROFILE: DEVICE address of 64 uint64 counters (else 0) */
-    uint64_t sample_buffer_bytes;   /* budget of the per-sample radiance buffer (16 B per pixel sample of this rank);
-                                     * 0 = default (all ns samples when they fit 48 GiB and 3/4 of the free HBM);
+    uint64_t sample_buffer_bytes;   /* budget of the per-sample radiance buffer (RTMI_SAMPLE_SLOT_BYTES per pixel sample of this rank);
+                                     * 0 = default (all ns samples when they fit 45 GiB and 3/4 of the free HBM);
                                      * a smaller budget renders the sample range in passes — same result */
     /* Progress callback (replaces the reference's stand-alone bar, src/progressbar.rs:6-58, which only sleeps): the
      * blocking entry points (rtmi_render, rtmi_render_multi) call it from the calling thread about every 50 ms while
@@ -304,7 +306,7 @@ void rtmi_scene_destroy(rtmi_scene *scene);
 uint32_t rtmi_local_tiles(const rtmi_render_params *p);
 
 /* Optional: allocate everything a later rtmi_render_device/rtmi_render call with the same params needs (the
- * per-sample radiance buffer, 16 B x local pixels x samples per pass, and the f64 sums), so that the first
+ * per-sample radiance buffer, RTMI_SAMPLE_SLOT_BYTES x local pixels x samples per pass, and the f64 sums), so that the first
  * render call does not pay for the allocation.  Idempotent; render calls allocate on demand anyway. */
 int rtmi_render_prepare(rtmi_scene *scene, const rtmi_render_params *params);
 

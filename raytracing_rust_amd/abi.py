@@ -23,6 +23,7 @@ RTMI_FLAG_ASYNC = 16
 RTMI_FLAG_SKY = 32
 RTMI_FLAG_REF_TREE = 64
 RTMI_FLAG_BLOCK_COOP = 32768
+RTMI_SAMPLE_SLOT_BYTES = 12  # per-sample radiance buffer: three fp32 per finished path
 RTMI_KERNEL_PERLANE, RTMI_KERNEL_WAVE_COOP, RTMI_KERNEL_ASYNC, RTMI_KERNEL_BLOCK_COOP = 0, 1, 2, 3
 RTMI_FLAG_FACE_FORWARD = 128
 RTMI_FLAG_UV_BOOK = 4096

@@ -56,7 +56,7 @@ struct rtmi_scene {
     rtmi_scene_desc meta{}; // counts only (pointers nulled)
     double *partial = nullptr; // f64 radiance sums [local tile][3][64], carried between passes
     size_t partial_bytes = 0;
-    float4 *samples = nullptr; // per-sample radiance [local tile][pass samples][64]
+    Rad3 *samples = nullptr; // per-sample radiance [local tile][pass samples][64], 12-B slots
     size_t samples_bytes = 0;
     uint2 *spill = nullptr;    // global part of the cooperative traversal stacks [wavefront slot][spill_cap]
     size_t spill_bytes = 0;
@@ -439,13 +439,13 @@ static int check_params(const rtmi_render_params *p) {
 // Plan of one render call: unit size, samples per pass; (re)allocates the per-sample buffer and the f64 sums.
 static int plan_and_reserve(rtmi_scene *s, const rtmi_render_params *p, uint32_t ntiles_local, uint32_t &chunk_spp,
                             uint32_t &pass_ns) {
-    // ---- per-sample buffer and passes.  Every finished path stores its radiance (16 B) in
+    // ---- per-sample buffer and passes.  Every finished path stores its radiance (12 B) in
     // samples[local tile][sample of the pass][pixel]; the resolve kernel adds them in sample order.  With
-    // 288 GB of HBM the whole sample range normally fits (headline: 33 GB); otherwise the range is rendered
+    // 288 GB of HBM the whole sample range normally fits (headline: 25 GB); otherwise the range is rendered
     // in passes and the f64 sums are carried between them — the same additions in the same order.
-    const size_t per_sample = (size_t)ntiles_local * 64 * sizeof(float4);
-    size_t want = p->sample_buffer_bytes ? (size_t)p->sample_buffer_bytes : ((size_t)48 << 30);
-    if (want > ((size_t)60 << 30)) want = (size_t)60 << 30; // slots are addressed with 32 bits (< 2^32 x 16 B)
+    const size_t per_sample = (size_t)ntiles_local * 64 * RTMI_SAMPLE_SLOT_BYTES;
+    size_t want = p->sample_buffer_bytes ? (size_t)p->sample_buffer_bytes : ((size_t)45 << 30);
+    if (want > ((size_t)45 << 30)) want = (size_t)45 << 30; // slots are addressed with 32 bits (< 2^32 x 12 B = 48 GiB)
     uint64_t max_pass = want / per_sample;
     if (max_pass < 1) max_pass = 1;
     if (max_pass > p->ns) max_pass = p->ns;

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
 // per local texel.  One thread per (local tile, pixel): adds this pass's samples to the f64 sum (`acc`, carried
 // between passes when the per-sample buffer does not hold all ns samples at once) and, on the last pass, writes
 // the texel.  A wavefront reads 1 KB contiguous per sample.
-__global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restrict__ samples, double *__restrict__ acc,
+__global__ __launch_bounds__(256) void rtmi_resolve_kernel(const Rad3 *__restrict__ samples, double *__restrict__ acc,
                                                            rtmi_texel *__restrict__ out, DevParams P, int first, int last,
                                                            int partial) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -689,18 +689,18 @@ __global__ __launch_bounds__(256) void rtmi_resolve_kernel(const float4 *__restr
     double *a = acc + ((size_t)ltile * 3) * 64 + lane;
     if (!first) { sum[0] = a[0]; sum[1] = a[64]; sum[2] = a[128]; }
     if (in_image) {
-        const float4 *src = samples + ((size_t)ltile * P.pass_stride) * 64u + lane;
+        const Rad3 *src = samples + ((size_t)ltile * P.pass_stride) * 64u + lane;
         uint32_t s = 0;
         for (; s + 8u <= P.pass_cnt; s += 8u) { // 8 independent loads in flight, additions in sample order
-            float4 v[8];
+            Rad3 v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = src[(size_t)(s + k) * 64u];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { sum[0] += (double)v[k].x; sum[1] += (double)v[k].y; sum[2] += (double)v[k].z; }
+            for (int k = 0; k < 8; k++) { sum[0] += (double)v[k].r; sum[1] += (double)v[k].g; sum[2] += (double)v[k].b; }
         }
         for (; s < P.pass_cnt; s++) {
-            const float4 v = src[(size_t)s * 64u];
-            sum[0] += (double)v.x; sum[1] += (double)v.y; sum[2] += (double)v.z;
+            const Rad3 v = src[(size_t)s * 64u];
+            sum[0] += (double)v.r; sum[1] += (double)v.g; sum[2] += (double)v.b;
         }
     }
     if (!last) {

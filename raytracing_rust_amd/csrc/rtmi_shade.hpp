@@ -537,5 +537,5 @@ __device__ __forceinline__ bool work_take(WaveWork &w, bool &queue_empty, bool w
 }
 // `col += color(..)` — tests/test.rs:69: the path's radiance goes to its slot of the per-sample buffer
 __device__ __forceinline__ void path_end(const DevParams &P, uint32_t oidx, const Path &pa) {
-    P.samples[oidx] = make_float4(pa.L.x, pa.L.y, pa.L.z, 0.0f);
+    P.samples[oidx] = Rad3{pa.L.x, pa.L.y, pa.L.z};
 }

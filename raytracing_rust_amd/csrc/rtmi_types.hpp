@@ -70,6 +70,11 @@ struct DevScene {
     uint32_t has_medium_outer; // some medium sits inside transforms of its item (RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT)
 };
 
+// one slot of the per-sample radiance buffer: three fp32, 12 bytes, written by one global_store_dwordx3 (a float4 slot
+// carried a padding word: a quarter of the buffer and of the resolve kernel's reads)
+struct Rad3 { float r, g, b; };
+static_assert(sizeof(Rad3) == RTMI_SAMPLE_SLOT_BYTES, "per-sample slot size is part of rtmi.h");
+
 struct DevCamera {
     F3 origin, llc, horizontal, vertical, u, v;
     float time0, time1, lens_radius;
@@ -82,7 +87,7 @@ struct DevParams {
     uint32_t tile_rank, tile_world, tiles_x, ntiles_local;
     uint32_t nchunks, chunk_spp;               // sample chunks of this pass: chunk c = [pass_s0 + c*chunk_spp, ..)
     uint32_t pass_s0, pass_cnt, pass_stride;   // this launch renders samples [pass_s0, pass_s0 + pass_cnt)
-    float4 *samples;                           // [local tile][pass_stride][64] radiance of every finished path
+    Rad3 *samples;                             // [local tile][pass_stride][64] radiance of every finished path (12 B)
     unsigned long long *path_sig;
     unsigned long long *prof;
     uint32_t stack_depth;

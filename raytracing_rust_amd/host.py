@@ -196,7 +196,7 @@ class Scene:
         return abi.load_rtmi().rtmi_local_tiles(C.byref(params))
 
     def prepare(self, params):
-        """Allocate the render buffers for `params` now (per-sample buffer: 16 B x local pixels x samples per pass)."""
+        """Allocate the render buffers for `params` now (per-sample buffer: 12 B x local pixels x samples per pass)."""
         self.host._check(self.host.lib.rth_render_prepare(self.h, C.byref(params)))
         return self
 

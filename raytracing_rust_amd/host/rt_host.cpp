@@ -570,10 +570,6 @@ static const Hittable *strip_wrappers(const Hittable *h, bool &flip, std::vector
         return h;
     }
 }
-static bool is_device_primitive(const Hittable *h) {
-    return dynamic_cast<const Sphere *>(h) || dynamic_cast<const MovingSphere *>(h) || dynamic_cast<const Rect *>(h) ||
-           dynamic_cast<const Cube *>(h);
-}
 // A primitive that can never report a hit, whatever the ray: a Rect with x0 > x1 or y0 > y1 (rect.rs:51 rejects every
 // x) — final_scene's light is one (tests/test.rs:444-452).  Its test has no side effect (no random draw), so the
 // members of a list scan that can never be hit are left out of the flat scene: the scan returns what it returned.

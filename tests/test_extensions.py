@@ -161,7 +161,7 @@ def test_progress_callback_counts_units_and_can_cancel(host):
     assert np.array_equal(img["linear"], plain["linear"])  # the callback changes nothing
     # several passes (small sample buffer): the count still runs to the same total
     seen.clear()
-    sc.render(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL, sample_buffer_bytes=80 * 45 * 64 * 16 * 48,
+    sc.render(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL, sample_buffer_bytes=80 * 45 * 64 * abi.RTMI_SAMPLE_SLOT_BYTES * 48,
               progress=lambda d, t: seen.append((d, t)) and False)
     assert seen[-1][0] == seen[-1][1] and all(a[0] <= b[0] for a, b in zip(seen, seen[1:]))
     with pytest.raises(HostError) as e:

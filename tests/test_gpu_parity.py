@@ -106,7 +106,7 @@ def test_result_independent_of_chunking_and_tiling(host):
         assert np.array_equal(base["rgb8"], other["rgb8"])
         assert np.array_equal(base["linear"], other["linear"])  # samples are added in sample order whatever the chunking
     # a per-sample buffer smaller than ns samples: the range is rendered in passes, sums carried in f64
-    per_sample = 9 * 5 * 64 * 16  # local tiles x 64 pixels x 16 B
+    per_sample = 9 * 5 * 64 * abi.RTMI_SAMPLE_SLOT_BYTES  # local tiles x 64 pixels x one slot
     for budget, chunks in ((per_sample * 5, 0), (per_sample * 1, 0), (per_sample * 7, 4)):
         other = sc.render(cam, nx, ny, ns, seed=5, spp_chunks=chunks, sample_buffer_bytes=budget, sig=True)
         assert np.array_equal(base["rgb8"], other["rgb8"]), budget

@@ -26,7 +26,7 @@ def test_partial_images_are_prefix_renders(host):
     nx, ny, ns = 1280, 720, 384
     cam, world = scenes_extra.build(host, "lit_final_scene", nx, ny, seed=1)
     sc = host.lower(world).upload(0)
-    per_sample = ((nx + 7) // 8) * ((ny + 7) // 8) * 64 * 16
+    per_sample = ((nx + 7) // 8) * ((ny + 7) // 8) * 64 * abi.RTMI_SAMPLE_SLOT_BYTES
     pass_spp = 32  # 12 passes
     seen = []
 
