@@ -385,7 +385,7 @@ def main():
         params = rdist.rank_params(nx, ny, ns, rank, world, seed=42, flags=args.flags, spp_chunks=args.chunks,
                                    shade_threshold=args.shade_threshold, sample_buffer_bytes=args.sample_buffer_mb << 20)
         local = rdist.new_local_framebuffer(params, device)
-        scene.prepare(params)  # per-sample radiance buffer (33 GB at the headline size) allocated before any timed step
+        scene.prepare(params)  # per-sample radiance buffer (25 GB at the headline size) allocated before any timed step
         render_ms = []  # the render kernel alone: HIP events recorded inside librtmi on the launch stream
 
         def step(events=None):

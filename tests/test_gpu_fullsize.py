@@ -45,7 +45,7 @@ def test_chunking_invariance_full_resolution(host):
 @pytest.mark.parametrize("rank", [0, 5])
 def test_c5_per_rank_workload_of_the_8_gpu_config(host, rank):
     """BASELINE config C5: final_scene 1920x1080x5000spp tile-split over 8 GPUs.  One rank's share (every 8th tile,
-    5000 spp: 1.3 G paths, 20.7 GB per-sample buffer) rendered on this GPU exactly as rank `rank` of 8 would:
+    5000 spp: 1.3 G paths, 15.6 GB per-sample buffer) rendered on this GPU exactly as rank `rank` of 8 would:
     pruned/cooperative == exact bit-for-bit in radiance, quantised texels and path signatures."""
     import torch
 

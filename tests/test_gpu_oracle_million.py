@@ -24,7 +24,7 @@ NX, NY, NS = 256, 144, 56  # 2.06 M paths; 576 tiles x 4 chunks of the unit queu
 @pytest.mark.parametrize("name,budget", [
     ("two_spheres", 0),          # C1
     ("random_spheres", 0),       # C2
-    ("cornell_box", 8 << 20),    # C3, per-sample buffer budget 8 MiB of the 33 MB needed: 5 passes, sums carried in f64
+    ("cornell_box", 8 << 20),    # C3, per-sample buffer budget 8 MiB of the 25 MB needed: passes, sums carried in f64
     ("cornell_smoke", 0),        # C4
     ("final_scene", 12 << 20),   # C5, 3 passes
     ("lit_final_scene", 0),      # C5's object graph with reachable emitters: every material reaches the pixels
