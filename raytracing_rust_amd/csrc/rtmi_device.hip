@@ -1149,7 +1149,8 @@ extern "C" int rtmi_multi_render(rtmi_multi *m, const rtmi_camera *cam, const rt
         RCCL_TRY(g_rccl.GroupStart());
         for (uint32_t i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(m->devices[i]));
-            RCCL_TRY(g_rccl.Gather(m->texels[i], i == 0 ? m->gathered : nullptr, stride * sizeof(rtmi_texel), /*ncclInt8*/ 0, 0, m->comms[i], m->scenes[i]->stream));
+            // (recvbuff is read on the root only; the others pass a valid device pointer rather than NULL for argument checkers)
+            RCCL_TRY(g_rccl.Gather(m->texels[i], i == 0 ? m->gathered : m->texels[i], stride * sizeof(rtmi_texel), /*ncclInt8*/ 0, 0, m->comms[i], m->scenes[i]->stream));
         }
         RCCL_TRY(g_rccl.GroupEnd());
     } else {
