@@ -230,3 +230,24 @@ def test_render_multi_rejects_bad_arguments_without_a_device(host):
         assert lib.rtmi_render_multi(C.byref(d), dev, 2, C.byref(c), C.byref(p), lin.ctypes.data, None, None) == 3  # RTMI_ERR_DEVICE
         assert b"no HIP device" in lib.rtmi_last_error()
         assert lib.rtmi_scene_status(None, None) == 1
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI (no C++ in the signatures): both public headers compile as C99 with -pedantic, and a C
+    translation unit that includes them links against librtmi.so and reads the ABI version."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    for h in ("rtmi.h", "rtmi_math.h"):
+        subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, h)], check=True)
+    src = tmp_path / "use.c"
+    src.write_text('#include <stdio.h>\n#include "rtmi.h"\n'
+                   'int main(void) { rtmi_render_params p; rtmi_scene_desc d; (void)p; (void)d;\n'
+                   '  printf("%u %d\\n", (unsigned)RTMI_ABI_VERSION, rtmi_device_count() >= 0); return 0; }\n')
+    exe = tmp_path / "use"
+    libdir = os.path.dirname(abi.lib_path("librtmi.so")) if hasattr(abi, "lib_path") else os.path.join(root, "raytracing_rust_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lrtmi", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.decode().split()
+    assert int(out[0]) == abi.RTMI_ABI_VERSION and out[1] == "1"
