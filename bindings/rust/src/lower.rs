@@ -106,6 +106,7 @@ fn contains_moving(h: &Rc<HittableDesc>) -> bool {
     match &**strip_wrappers(h, &mut dummy, None) {
         HittableDesc::MovingSphere { .. } => true,
         HittableDesc::Bvh { left, right, .. } => contains_moving(left) || contains_moving(right),
+        HittableDesc::List { list } => list.iter().any(contains_moving), // a list that sits as a BVH child (lower_list_leaf)
         _ => false,
     }
 }
@@ -120,6 +121,11 @@ fn moving_time_range(h: &Rc<HittableDesc>, lo: &mut f32, hi: &mut f32) {
             moving_time_range(left, lo, hi);
             moving_time_range(right, lo, hi);
         }
+        HittableDesc::List { list } => {
+            for m in list {
+                moving_time_range(m, lo, hi);
+            }
+        }
         _ => {}
     }
 }
@@ -129,6 +135,22 @@ fn true_bounds(h: &Rc<HittableDesc>) -> Option<Aabb> {
     let mut dummy = false;
     let mut chain: Vec<RtmiXform> = Vec::new();
     let inner = strip_wrappers(h, &mut dummy, Some(&mut chain));
+    if let HittableDesc::List { list } = &**inner {
+        // a list as a BVH child: the union of what its members can report
+        if !chain.is_empty() {
+            return None;
+        }
+        let mut out: Option<Aabb> = None;
+        for m in list {
+            if let Some(mb) = true_bounds(m) {
+                out = Some(match out {
+                    Some(o) => surrounding_box(&o, &mb),
+                    None => mb,
+                });
+            }
+        }
+        return out;
+    }
     let ib = true_bounds_inner(inner)?;
     if chain.is_empty() {
         return Some(ib);
@@ -408,29 +430,16 @@ impl SceneBuilder {
                 let (a, b) = put_box(sub_box);
                 mn = a;
                 mx = b;
+            } else if let HittableDesc::List { list } = &**h {
+                // a HittableList as a child (bvh.rs:11-12 takes any Hittable): a subtree of always-passing nodes over its members
+                let (r, cb) = self.lower_list_leaf(list, bbox, depth + 1, flip != flip_all, force_moving, pad, unbounded_leaves)?;
+                child[c] = r;
+                let (a, b) = put_box(&cb);
+                mn = a;
+                mx = b;
             } else {
-                let prim = self.push_prim(h, flip != flip_all, force_moving)?;
-                child[c] = leaf_ref(self.out.prim_meta[prim].r#type, prim);
-                // gate = the box of THIS node, the leaf's parent in the reference tree, rounded like every node box
-                let (gmn, gmx) = put_box(bbox);
-                let g = &mut self.out.prim_gate[prim * 8..prim * 8 + 8];
-                g[0] = gmn[0]; g[1] = gmn[1]; g[2] = gmn[2];
-                g[4] = gmx[0]; g[5] = gmx[1]; g[6] = gmx[2];
-                let tb = true_bounds(h);
-                self.prim_box[prim] = tb;
-                // A leaf child has no box test in the reference (bvh.rs:72-73).  The box stored here only serves the
-                // fast-cull prefilter: the primitive's TRUE extent (|radius|) padded by `pad`; unbounded for moving
-                // spheres and for Rect.
-                let big = F32_MAX as f64;
-                let mut lb = Aabb { min: [-big; 3], max: [big; 3] };
-                let mut dummy2 = false;
-                let inner = strip_wrappers(h, &mut dummy2, None);
-                let plain = !matches!(&**inner, HittableDesc::MovingSphere { .. } | HittableDesc::Rect { .. });
-                if !unbounded_leaves && plain {
-                    if let Some(t) = tb {
-                        lb = pad_box(&t, pad);
-                    }
-                }
+                let (r, lb) = self.lower_leaf(h, bbox, flip != flip_all, force_moving, pad, unbounded_leaves)?;
+                child[c] = r;
                 let (a, b) = put_box(&lb);
                 mn = a;
                 mx = b;
@@ -447,6 +456,103 @@ impl SceneBuilder {
         self.out.nodes[id].left = child[0];
         self.out.nodes[id].right = child[1];
         Ok(id as i32)
+    }
+
+    /// One primitive as a leaf below the reference node whose box is `holder`: its planes, its gate (that box), its
+    /// culling box (rt_host.cpp lower_leaf).
+    fn lower_leaf(&mut self, h: &Rc<HittableDesc>, holder: &Aabb, flip: bool, force_moving: bool, pad: f64, unbounded_leaves: bool) -> Result<(i32, Aabb), LowerError> {
+        let prim = self.push_prim(h, flip, force_moving)?;
+        let r = leaf_ref(self.out.prim_meta[prim].r#type, prim);
+        // gate = the box of the holding node, the leaf's parent in the reference tree, rounded like every node box
+        let (gmn, gmx) = put_box(holder);
+        let g = &mut self.out.prim_gate[prim * 8..prim * 8 + 8];
+        g[0] = gmn[0]; g[1] = gmn[1]; g[2] = gmn[2];
+        g[4] = gmx[0]; g[5] = gmx[1]; g[6] = gmx[2];
+        let tb = true_bounds(h);
+        self.prim_box[prim] = tb;
+        // A leaf child has no box test in the reference (bvh.rs:72-73).  The box stored here only serves the fast-cull
+        // prefilter: the primitive's TRUE extent (|radius|) padded by `pad`; unbounded for moving spheres and for Rect.
+        let big = F32_MAX as f64;
+        let mut lb = Aabb { min: [-big; 3], max: [big; 3] };
+        let mut dummy2 = false;
+        let inner = strip_wrappers(h, &mut dummy2, None);
+        let plain = !matches!(&**inner, HittableDesc::MovingSphere { .. } | HittableDesc::Rect { .. });
+        if !unbounded_leaves && plain {
+            if let Some(t) = tb {
+                lb = pad_box(&t, pad);
+            }
+        }
+        Ok((r, lb))
+    }
+
+    /// A HittableList as the child of a BVHNode (rt_host.cpp lower_list_leaf).  The reference scans the members with a
+    /// shrinking t_max (hittable.rs:37-47): smallest t wins, and on an exact tie the LAST rect-like member among the tied
+    /// ones (Rect / Cube report at t == t_max, rect.rs:47), else the FIRST sphere (sphere.rs:44).  The BVH fold is
+    /// "smallest t, ties -> the later leaf": the members are numbered spheres in reverse order, then rect-likes in order,
+    /// below a balanced subtree of nodes whose boxes pass every ray.  Nested lists are flattened.
+    fn lower_list_leaf(&mut self, list: &[Rc<HittableDesc>], holder: &Aabb, depth: u32, flip: bool, force_moving: bool, pad: f64,
+                       unbounded_leaves: bool) -> Result<(i32, Aabb), LowerError> {
+        fn flatten(list: &[Rc<HittableDesc>], flip: bool, out: &mut Vec<(Rc<HittableDesc>, bool)>) {
+            for m in list {
+                let mut f = flip;
+                let h = strip_flips(m, &mut f);
+                if let HittableDesc::List { list: sub } = &**h {
+                    flatten(sub, f, out);
+                } else {
+                    out.push((h.clone(), f));
+                }
+            }
+        }
+        let is_sphere = |h: &Rc<HittableDesc>| {
+            let mut d = false;
+            matches!(&**strip_wrappers(h, &mut d, None), HittableDesc::Sphere { .. } | HittableDesc::MovingSphere { .. })
+        };
+        let mut members = Vec::new();
+        flatten(list, flip, &mut members);
+        if members.is_empty() {
+            return Err(LowerError::Panic("BVHNode over an empty HittableList: no bounding box (bvh.rs:30)".into()));
+        }
+        let mut ordered: Vec<(Rc<HittableDesc>, bool)> = members.iter().rev().filter(|m| is_sphere(&m.0)).cloned().collect();
+        for m in &members {
+            if is_sphere(&m.0) {
+                continue;
+            }
+            let mut d = false;
+            if !matches!(&**strip_wrappers(&m.0, &mut d, None), HittableDesc::Rect { .. } | HittableDesc::Cube { .. }) {
+                return Err(LowerError::Unsupported(
+                    "a HittableList that is a BVH leaf may hold primitives (also wrapped in Traslate / Rotate / FlipNormals) and lists of them only".into()));
+            }
+            ordered.push(m.clone());
+        }
+        // leaves first (consecutive primitive numbers in the order above), then the subtree over them
+        let mut refs = Vec::with_capacity(ordered.len());
+        let mut boxes = Vec::with_capacity(ordered.len());
+        for (h, f) in &ordered {
+            let (r, b) = self.lower_leaf(h, holder, *f, force_moving, pad, unbounded_leaves)?;
+            refs.push(r);
+            boxes.push(b);
+        }
+        Ok(self.list_subtree(&refs, &boxes, 0, refs.len(), depth))
+    }
+    fn list_subtree(&mut self, refs: &[i32], boxes: &[Aabb], lo: usize, hi: usize, depth: u32) -> (i32, Aabb) {
+        if hi - lo == 1 {
+            return (refs[lo], boxes[lo]);
+        }
+        if depth > self.out.max_bvh_depth {
+            self.out.max_bvh_depth = depth;
+        }
+        let id = self.out.nodes.len();
+        self.out.nodes.push(RtmiBvhNode { lmin: [0.0; 3], lmax: [0.0; 3], rmin: [0.0; 3], rmax: [0.0; 3], left: 0, right: 0, pad: [0; 2] });
+        let mid = lo + (hi - lo) / 2;
+        let (cl, bl) = self.list_subtree(refs, boxes, lo, mid, depth + 1);
+        let (cr, br) = self.list_subtree(refs, boxes, mid, hi, depth + 1);
+        let (lmin, lmax) = put_box(&bl);
+        let (rmin, rmax) = put_box(&br);
+        let me = &mut self.out.nodes[id];
+        me.lmin = lmin; me.lmax = lmax; me.rmin = rmin; me.rmax = rmax;
+        me.left = cl; me.right = cr;
+        let big = F32_MAX as f64;
+        (id as i32, Aabb { min: [-big; 3], max: [big; 3] }) // an internal node of the list: no box test in the reference
     }
 
     /// Binned-SAH tree over the primitives' true extents (rt_host.cpp build_alt_tree).  Returns a child reference

@@ -584,6 +584,10 @@ static bool contains_moving(const Hittable *h) {
     h = strip_wrappers(h, dummy, nullptr);
     if (dynamic_cast<const MovingSphere *>(h)) return true;
     if (auto n = dynamic_cast<const BVHNode *>(h)) return contains_moving(n->left_.get()) || contains_moving(n->right_.get());
+    if (auto l = dynamic_cast<const HittableList *>(h)) { // a list that sits as a BVH child (lower_list_leaf)
+        for (const auto &m : l->items())
+            if (contains_moving(m.get())) return true;
+    }
     return false;
 }
 
@@ -682,6 +686,17 @@ static bool true_bounds(const Hittable *h, AABB &out) {
     bool dummy = false;
     std::vector<rtmi_xform> chain;
     const Hittable *inner = strip_wrappers(h, dummy, &chain);
+    if (auto l = dynamic_cast<const HittableList *>(inner)) { // a list as a BVH child: the union of what its members can report
+        if (!chain.empty()) return false;
+        bool any = false;
+        for (const auto &m : l->items()) {
+            AABB mb(Vec3(0, 0, 0), Vec3(0, 0, 0));
+            if (!true_bounds(m.get(), mb)) continue;
+            out = any ? surrounding_box(out, mb) : mb;
+            any = true;
+        }
+        return any;
+    }
     AABB ib(Vec3(0, 0, 0), Vec3(0, 0, 0));
     if (!true_bounds_inner(inner, ib)) return false;
     if (chain.empty()) { out = ib; return true; }
@@ -752,6 +767,8 @@ static void moving_time_range(const Hittable *h, float &lo, float &hi) {
     } else if (auto n = dynamic_cast<const BVHNode *>(h)) {
         moving_time_range(n->left_.get(), lo, hi);
         moving_time_range(n->right_.get(), lo, hi);
+    } else if (auto l = dynamic_cast<const HittableList *>(h)) {
+        for (const auto &m : l->items()) moving_time_range(m.get(), lo, hi);
     }
 }
 
@@ -776,36 +793,15 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
             child[c] = lower_bvh(*sub, depth + 1, force_moving, pad, unbounded_leaves, flip_all != flip);
             rtmi_bvh_node &me = out.nodes[(size_t)id];
             put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, sub->bbox_);
+        } else if (auto lst = dynamic_cast<const HittableList *>(h)) {
+            // a HittableList as a child (bvh.rs:11-12 takes any Hittable): a subtree of always-passing nodes over its members
+            AABB cb(Vec3(0, 0, 0), Vec3(0, 0, 0));
+            child[c] = lower_list_leaf(*lst, n, depth + 1, flip != flip_all, force_moving, pad, unbounded_leaves, cb);
+            rtmi_bvh_node &me = out.nodes[(size_t)id];
+            put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, cb);
         } else {
-            const int prim = push_prim(*h, flip != flip_all, force_moving);
-            child[c] = RTMI_LEAF(out.prim_meta[(size_t)prim].type, prim);
-            { // gate = the box of THIS node, the leaf's parent in the reference tree, rounded like every node box
-                float gmn[3], gmx[3];
-                put_box(gmn, gmx, n.bbox_);
-                float *g = &out.prim_gate[(size_t)prim * 8];
-                g[0] = gmn[0]; g[1] = gmn[1]; g[2] = gmn[2]; g[4] = gmx[0]; g[5] = gmx[1]; g[6] = gmx[2];
-                AABB tbx(Vec3(0, 0, 0), Vec3(0, 0, 0));
-                if (true_bounds(h, tbx)) { out.prim_box[(size_t)prim] = tbx; out.prim_has_box[(size_t)prim] = 1; }
-            }
-            // A leaf child has no box test in the reference (bvh.rs:72-73).  The box stored here is
-            // used only by the fast-cull prefilter, so it must contain every hit the primitive's own
-            // fp32 test can report, at EVERY ray time: the exact box padded by `pad` for static
-            // primitives, unbounded for moving spheres and for Rect (whose bounding_box ignores
-            // the plane, rect.rs:72-73).
-            const double big = 3.40282346638528859811704183484516925e+38;
-            AABB lb(Vec3(-big, -big, -big), Vec3(big, big, big));
-            bool dummy2 = false;
-            const Hittable *inner = strip_wrappers(h, dummy2, nullptr);
-            if (!unbounded_leaves && !dynamic_cast<const MovingSphere *>(inner) && !dynamic_cast<const Rect *>(inner)) {
-                // the primitive's TRUE extent (|radius| for a sphere), not bounding_box(): Sphere::bounding_box of a
-                // negative radius (the hollow-glass idiom) is an inverted box that no ray passes, and the reference has
-                // no leaf box test at all (bvh.rs:72-73)
-                AABB tl(Vec3(0, 0, 0), Vec3(0, 0, 0));
-                if (true_bounds(h, tl)) {
-                    const Vec3 pd(pad, pad, pad);
-                    lb = AABB(tl.min - pd, tl.max + pd);
-                }
-            }
+            AABB lb(Vec3(0, 0, 0), Vec3(0, 0, 0));
+            child[c] = lower_leaf(*h, n, flip != flip_all, force_moving, pad, unbounded_leaves, lb);
             rtmi_bvh_node &me = out.nodes[(size_t)id];
             put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, lb);
         }
@@ -813,6 +809,100 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
     out.nodes[(size_t)id].left = child[0];
     out.nodes[(size_t)id].right = child[1];
     return id;
+}
+
+// One primitive as a leaf below the reference node `n`: its planes, its gate (the box of `n`), its culling box `lb`.
+int32_t SceneBuilder::lower_leaf(const Hittable &hh, const BVHNode &n, bool flip, bool force_moving, double pad, bool unbounded_leaves,
+                                 AABB &lb) {
+    const Hittable *h = &hh;
+    const int prim = push_prim(*h, flip, force_moving);
+    const int32_t ref = RTMI_LEAF(out.prim_meta[(size_t)prim].type, prim);
+    { // gate = the box of THIS node, the leaf's parent in the reference tree, rounded like every node box
+        float gmn[3], gmx[3];
+        put_box(gmn, gmx, n.bbox_);
+        float *g = &out.prim_gate[(size_t)prim * 8];
+        g[0] = gmn[0]; g[1] = gmn[1]; g[2] = gmn[2]; g[4] = gmx[0]; g[5] = gmx[1]; g[6] = gmx[2];
+        AABB tbx(Vec3(0, 0, 0), Vec3(0, 0, 0));
+        if (true_bounds(h, tbx)) { out.prim_box[(size_t)prim] = tbx; out.prim_has_box[(size_t)prim] = 1; }
+    }
+    // A leaf child has no box test in the reference (bvh.rs:72-73).  The box stored here is
+    // used only by the fast-cull prefilter, so it must contain every hit the primitive's own
+    // fp32 test can report, at EVERY ray time: the exact box padded by `pad` for static
+    // primitives, unbounded for moving spheres and for Rect (whose bounding_box ignores
+    // the plane, rect.rs:72-73).
+    const double big = 3.40282346638528859811704183484516925e+38;
+    lb = AABB(Vec3(-big, -big, -big), Vec3(big, big, big));
+    bool dummy2 = false;
+    const Hittable *inner = strip_wrappers(h, dummy2, nullptr);
+    if (!unbounded_leaves && !dynamic_cast<const MovingSphere *>(inner) && !dynamic_cast<const Rect *>(inner)) {
+        // the primitive's TRUE extent (|radius| for a sphere), not bounding_box(): Sphere::bounding_box of a
+        // negative radius (the hollow-glass idiom) is an inverted box that no ray passes, and the reference has
+        // no leaf box test at all (bvh.rs:72-73)
+        AABB tl(Vec3(0, 0, 0), Vec3(0, 0, 0));
+        if (true_bounds(h, tl)) {
+            const Vec3 pd(pad, pad, pad);
+            lb = AABB(tl.min - pd, tl.max + pd);
+        }
+    }
+    return ref;
+}
+
+// A HittableList as the child of a BVHNode (bvh.rs:11-12: children are any Rc<dyn Hittable>; its bounding box is the
+// union of its members', hittable.rs:49-64).  The reference scans the members in order with a shrinking t_max
+// (hittable.rs:37-47): the result is the member with the smallest t, and on an exact tie the LAST rect-like member among
+// the tied ones if there is one (Rect / Cube report at t == t_max, rect.rs:47), else the FIRST sphere (Sphere reports only
+// below t_max, sphere.rs:44).  The BVH fold is "smallest t, ties -> the later leaf", so the members are numbered spheres in
+// reverse order first, then rect-likes in order, and hang below a balanced subtree of nodes whose boxes pass every ray (the
+// reference tests no box below the node that holds the list): same winner, bit for bit, from every kernel.  Their gate is
+// the box of the holding node, like any leaf's.  Nested lists are flattened (an inner scan continues the outer one).
+static void flatten_list_leaf(const HittableList &l, bool flip, std::vector<std::pair<const Hittable *, bool>> &members) {
+    for (const auto &m : l.items()) {
+        bool f = flip;
+        const Hittable *h = strip_flips(m.get(), f);
+        if (auto sub = dynamic_cast<const HittableList *>(h)) { flatten_list_leaf(*sub, f, members); continue; }
+        members.push_back({h, f});
+    }
+}
+int32_t SceneBuilder::lower_list_leaf(const HittableList &l, const BVHNode &holder, uint32_t depth, bool flip, bool force_moving,
+                                      double pad, bool unbounded_leaves, AABB &box_out) {
+    std::vector<std::pair<const Hittable *, bool>> members, ordered;
+    flatten_list_leaf(l, flip, members);
+    if (members.empty()) throw Panic("BVHNode over an empty HittableList: no bounding box (bvh.rs:30)");
+    for (size_t k = members.size(); k-- > 0;) { // spheres, last first
+        bool d = false;
+        const Hittable *in = strip_wrappers(members[k].first, d, nullptr);
+        if (dynamic_cast<const Sphere *>(in) || dynamic_cast<const MovingSphere *>(in)) ordered.push_back(members[k]);
+    }
+    for (const auto &m : members) { // then the rect-likes, first first
+        bool d = false;
+        const Hittable *in = strip_wrappers(m.first, d, nullptr);
+        if (dynamic_cast<const Sphere *>(in) || dynamic_cast<const MovingSphere *>(in)) continue;
+        if (!dynamic_cast<const Rect *>(in) && !dynamic_cast<const Cube *>(in))
+            throw Unsupported("a HittableList that is a BVH leaf may hold primitives (also wrapped in Traslate / Rotate / FlipNormals) and lists of them only");
+        ordered.push_back(m);
+    }
+    // leaves first (consecutive primitive numbers in the order above), then the subtree over them
+    std::vector<int32_t> refs(ordered.size());
+    std::vector<AABB> boxes(ordered.size(), AABB(Vec3(0, 0, 0), Vec3(0, 0, 0)));
+    for (size_t k = 0; k < ordered.size(); k++)
+        refs[k] = lower_leaf(*ordered[k].first, holder, ordered[k].second, force_moving, pad, unbounded_leaves, boxes[k]);
+    const double big = 3.40282346638528859811704183484516925e+38;
+    const AABB everything(Vec3(-big, -big, -big), Vec3(big, big, big));
+    std::function<int32_t(size_t, size_t, uint32_t, AABB &)> build = [&](size_t lo, size_t hi, uint32_t dp, AABB &bo) -> int32_t {
+        if (hi - lo == 1) { bo = boxes[lo]; return refs[lo]; }
+        if (dp > out.max_bvh_depth) out.max_bvh_depth = dp;
+        const int32_t id = (int32_t)out.nodes.size();
+        out.nodes.push_back(rtmi_bvh_node{});
+        const size_t mid = lo + (hi - lo) / 2;
+        AABB bl(Vec3(0, 0, 0), Vec3(0, 0, 0)), br(Vec3(0, 0, 0), Vec3(0, 0, 0));
+        const int32_t cl = build(lo, mid, dp + 1, bl), cr = build(mid, hi, dp + 1, br);
+        rtmi_bvh_node &me = out.nodes[(size_t)id];
+        put_box(me.lmin, me.lmax, bl); put_box(me.rmin, me.rmax, br);
+        me.left = cl; me.right = cr;
+        bo = everything; // an internal node of the list: no box test in the reference
+        return id;
+    };
+    return build(0, ordered.size(), depth, box_out);
 }
 
 // Alternative tree over the primitives [lo,hi) of `prims` for the pruned kernels: binned SAH on the primitives'

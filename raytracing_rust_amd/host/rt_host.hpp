@@ -363,6 +363,9 @@ class SceneBuilder {
     void lower_item(const Hittable &h);
     int push_prim(const Hittable &h, bool flip, bool force_moving);
     int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves, bool flip_all);
+    int32_t lower_leaf(const Hittable &h, const BVHNode &n, bool flip, bool force_moving, double pad, bool unbounded_leaves, AABB &lb);
+    int32_t lower_list_leaf(const HittableList &l, const BVHNode &holder, uint32_t depth, bool flip, bool force_moving, double pad,
+                            bool unbounded_leaves, AABB &box_out);
     int32_t build_alt_tree(std::vector<int> &prims, size_t lo, size_t hi, uint32_t depth, double pad, AABB *box_out);
     int32_t collapse_alt(int32_t ref, uint32_t depth); // binary scratch tree -> 4-wide nodes in out.alt_nodes
     std::vector<rtmi_bvh_node> alt_scratch_;            // binary SAH tree being built for the current item

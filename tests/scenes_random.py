@@ -111,11 +111,28 @@ def random_scene(api, seed, only=None, instanced=False):
             for _ in range(n):
                 p = inst(_prim(api, rng, extent=2.5, allow_moving=moving))
                 objs.append(api.FlipNormals(p) if rng.random() < 0.1 else p)
+            if instanced and n >= 3 and rng2.random() < 0.4:
+                # a HittableList as ONE object of the BVH (bvh.rs:11-12 takes any Hittable): two to five of the objects,
+                # sometimes one of them twice (an exact tie inside the scan), sometimes with a nested list, sometimes flipped
+                k0 = int(rng2.integers(0, n - 1))
+                k1 = min(n, k0 + int(rng2.integers(2, 6)))
+                grp = api.HittableList()
+                for q in objs[k0:k1]:
+                    grp.push(q)
+                if rng2.random() < 0.5:
+                    grp.push(objs[k0])
+                if rng2.random() < 0.3:
+                    sub = api.HittableList()
+                    sub.push(objs[k1 - 1])
+                    sub.push(objs[k0])
+                    grp.push(api.FlipNormals(sub) if rng2.random() < 0.5 else sub)
+                objs = objs[:k0] + [api.FlipNormals(grp) if rng2.random() < 0.2 else grp] + objs[k1:]
             if n > 6 and rng.random() < 0.3:  # a BVH built earlier as one of the objects of this one
-                inner = api.BVHNode(objs[:n // 2], 0.0, 1.0)
+                half = len(objs) // 2
+                inner = api.BVHNode(objs[:half], 0.0, 1.0)
                 if instanced and rng2.random() < 0.5:
                     inner = api.FlipNormals(inner)  # hittable.rs:67-88 around a subtree: every normal below is negated
-                objs = [inner] + objs[n // 2:]
+                objs = [inner] + objs[half:]
             world.push(_wrap(api, rng, api.BVHNode(objs, 0.0, 1.0)))
         else:  # a participating medium inside a (transformed) boundary; FlipNormals outside only
             b = api.Sphere(rng.uniform(-2, 2, 3), float(rng.uniform(0.8, 2.0)), api.Dielectric(1.5)) if rng.random() < 0.5 \

@@ -166,3 +166,69 @@ def test_pruned_equals_exact_when_boxes_are_not_trustworthy(host, orc32, case):
         assert np.array_equal(got["sig"], ref["sig"]), (case, flags)
         assert np.array_equal(got["linear"], ref["linear"]), (case, flags)
     orc32.free_all()
+
+
+def _list_leaf_world(api):
+    """A HittableList as a child of a BVHNode (bvh.rs:11-12 takes any Hittable), with exact ties inside the scan
+    (hittable.rs:37-47): two coincident spheres (the FIRST wins: Sphere reports only below t_max, sphere.rs:44), two
+    coincident rects (the LAST wins: Rect reports at t == t_max, rect.rs:47), a nested list with a cube and a flipped
+    sphere.  Every member emits its own colour, so the winner of a tie is in the pixels."""
+    red = api.DiffuseLight(api.SolidTexture(4.0, 0.2, 0.2))
+    green = api.DiffuseLight(api.SolidTexture(0.2, 4.0, 0.2))
+    blue = api.DiffuseLight(api.SolidTexture(0.2, 0.2, 4.0))
+    grey = api.Lambertian(api.SolidTexture(0.7, 0.7, 0.7))
+    lst = api.HittableList()
+    lst.push(api.Sphere((0.0, 0.5, 0.0), 0.5, red))
+    lst.push(api.Sphere((0.0, 0.5, 0.0), 0.5, green))
+    lst.push(api.Rect(api.PLANE_XY, -2.0, 0.0, -1.0, 1.0, 0.0, blue))
+    lst.push(api.Rect(api.PLANE_XY, -2.0, 0.0, -1.0, 1.0, 0.0, green))
+    inner = api.HittableList()
+    inner.push(api.Traslate(api.Cube((0.0, 0.0, -0.5), (1.0, 1.0, 0.5), grey), (1.0, 0.0, 0.0)))
+    inner.push(api.FlipNormals(api.Sphere((1.5, 1.4, 0.0), 0.4, red)))
+    lst.push(inner)
+    api.seed_scene_rng(3)
+    return api.BVHNode([lst, api.Sphere((0.0, -100.0, 0.0), 100.0, grey), api.Sphere((3.0, 0.5, 0.0), 0.5, grey),
+                        api.FlipNormals(api.Rect(api.PLANE_XY, -4.0, 0.0, 4.0, 3.0, -2.0, grey))], 0.0, 1.0)
+
+
+def test_list_as_bvh_leaf_lowers_in_tie_order(host):
+    a = host.lower(_list_leaf_world(host)).arrays()
+    meta, mats = a["prim_meta"], a["materials"]
+    emit = [tuple(round(float(x), 1) for x in (a["textures"][mats[m.material].tex].f0, a["textures"][mats[m.material].tex].f1,
+                                                a["textures"][mats[m.material].tex].f2)) for m in meta]
+    types = [m.type for m in meta]
+    # the list's members are numbered consecutively: spheres last-first (flipped red, green, red), then the rect-likes
+    # first-first (blue rect, green rect, cube) — "ties -> the later leaf" then picks the scan's winner
+    k = emit.index((0.2, 4.0, 0.2))  # the green sphere: second of its run
+    assert types[k - 1:k + 5] == [abi.PRIM_SPHERE, abi.PRIM_SPHERE, abi.PRIM_SPHERE, abi.PRIM_RECT, abi.PRIM_RECT, abi.PRIM_CUBE]
+    assert emit[k - 1][0] == 4.0 and meta[k - 1].flags & 1 and emit[k + 1][0] == 4.0 and not meta[k + 1].flags & 1
+    assert emit[k + 2] == (0.2, 0.2, 4.0) and emit[k + 3] == (0.2, 4.0, 0.2)
+    assert (meta[k + 4].flags >> abi.RTMI_PRIMFLAG_XF_COUNT_SHIFT) & 15 == 1
+    big = np.float32(3.4028235e38)
+    inner = [n for n in a["nodes"] if n.lmin[0] == -big and n.rmin[0] == -big]
+    assert inner  # nodes of the list: boxes that pass every ray (the reference tests none below the holding node)
+    gate = np.ctypeslib.as_array(host.lower(_list_leaf_world(host)).desc().prim_gate, shape=(len(meta), 8))
+    assert all(np.array_equal(gate[k - 1], gate[j]) for j in range(k, k + 5))  # one gate: the box of the holding node
+
+
+@pytest.mark.gpu
+def test_list_as_bvh_leaf_matches_the_fp32_oracle(host, orc32):
+    nx, ny, ns = 96, 64, 16
+    worlds, cams = [], []
+    for api in (host, orc32):
+        worlds.append(_list_leaf_world(api))
+        cams.append(api.Camera((0.5, 1.2, 6.0), (0.3, 0.6, 0.0), (0.0, 1.0, 0.0), 40.0, nx / ny, 0.05, 6.0, 0.0, 1.0))
+    sc = host.lower(worlds[0])
+    ref = orc32.render(cams[1], worlds[1], nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM)
+    lin = ref["linear"]
+    # the tie winners are visible: red (first sphere) dominates green where the coincident spheres are seen, and the
+    # coincident rects show green (the later one), not blue
+    assert float(lin[..., 0].max()) > 1.0 and float(lin[..., 1].max()) > 1.0
+    for flags in (0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_REF_TREE,
+                  abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_BLOCK_COOP,
+                  abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL):
+        got = sc.render(cams[0], nx, ny, ns, seed=42, flags=flags, sig=True)
+        assert np.array_equal(got["sig"], ref["sig"]), flags
+        assert np.array_equal(got["linear"], ref["linear"]), flags
+        assert np.array_equal(got["rgb8"].astype(np.int32), ref["rgb"]), flags
+    orc32.free_all()
