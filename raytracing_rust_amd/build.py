@@ -16,7 +16,7 @@ _ROOT = os.path.dirname(_PKG)
 LIB_DIR = os.environ.get("RTMI_LIB_DIR") or os.path.join(_PKG, "lib")
 INCLUDE = os.path.join(_ROOT, "include")
 
-RTMI_SRC = [os.path.join(_PKG, "csrc", "rtmi_device.hip")]
+RTMI_SRC = [os.path.join(_PKG, "csrc", "rtmi_device.hip"), os.path.join(_PKG, "csrc", "rtmi_lean.hip")]
 HOST_SRC = [os.path.join(_PKG, "host", "rt_host.cpp"), os.path.join(_PKG, "host", "rt_host_c.cpp")]
 RTMI_DEPS = RTMI_SRC + sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hpp"))) + [
     os.path.join(INCLUDE, "rtmi.h"), os.path.join(INCLUDE, "rtmi_math.h")]
@@ -47,13 +47,25 @@ def build_rtmi(force=False, verbose=False):
     # operand selection wrong in at least one place (hit point/normal of a sphere under Rotate about Z: every
     # pixel differed from the oracle, found by tests/test_random_scenes.py; fine with the function out of line,
     # fine without SLP).  The scalar code is also 2-3 % faster on this VALU-bound path.
+    # -amdgpu-sched-strategy=iterative-maxocc: the machine scheduler that first gets the register pressure under the
+    # occupancy target and then schedules for latency.  Same instructions (8.75 k static in the headline kernel either
+    # way), a better order: final_scene +2.4 %, random_spheres +1.7 % against the default strategy; max-ilp -1.2 %,
+    # max-memory-clause -1.4 %, iterative-ilp +0.6 %, iterative-minreg -6 % (profiles/r03_experiments/sched_strategy_ab.log).
     # RTMI_EXTRA_CFLAGS: experiment switches (-DRTMI_...) for A/B builds into another RTMI_LIB_DIR (tools/ab_build.sh)
+    # The lean instantiations of the cooperative kernel (scenes without BVH items) lose 2 % under that strategy: they are a
+    # translation unit of their own (csrc/rtmi_lean.hip) with the default one.
     extra = os.environ.get("RTMI_EXTRA_CFLAGS", "").split()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-           "-std=c++17", "-I" + INCLUDE] + extra + ["-o", LIBRTMI] + RTMI_SRC
+    sched = [] if os.environ.get("RTMI_DEFAULT_SCHED") else ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
+    common = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17",
+              "-I" + INCLUDE]
     if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.run(cmd, check=True)
+        common.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    objs = []
+    for src, flags in ((RTMI_SRC[0], sched), (RTMI_SRC[1], [])):
+        obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + ".o")
+        subprocess.run(common + flags + extra + ["-c", src, "-o", obj], check=True)
+        objs.append(obj)
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIBRTMI] + objs, check=True)
     return LIBRTMI
 
 

@@ -284,6 +284,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     }
 }
 
+#ifndef RTMI_LEAN_TU
+// the lean instantiations (EXT = false) are compiled in rtmi_lean.hip, with another machine-scheduler strategy
+extern template __global__ void rtmi_render_coop<false, false, 4, false, false>(DevScene, DevCamera, DevParams);
+extern template __global__ void rtmi_render_coop<false, false, 4, false, true>(DevScene, DevCamera, DevParams);
+#endif
+
 // ----------------------------------------------------------------------------------
 // render kernel, two-phase form with WORKGROUP-cooperative BVH traversal (rtmi_bvh_block.hpp).
 // Same per-lane program as rtmi_render_coop (items in list order, media draws in order: same bits); what changes is
@@ -669,6 +675,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_async(DevSce
     if (SIG && in_image) atomicAdd(P.path_sig + (size_t)w.ltile * 64 + lane, sig); // integer add: order-independent
 }
 
+#ifndef RTMI_LEAN_TU /* plain (non-template) kernels: defined once, in rtmi_device.hip */
 // `col += color(..)` in sample order, then `col /= ns; sqrt; clamp; (255.99*c) as i32` — tests/test.rs:69-78,
 // per local texel.  One thread per (local tile, pixel): adds this pass's samples to the f64 sum (`acc`, carried
 // between passes when the per-sample buffer does not hold all ns samples at once) and, on the last pass, writes
@@ -789,3 +796,4 @@ __global__ void rtmi_philox_probe_kernel(const uint32_t *ctr, const uint32_t *ke
     philox(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], key[2 * i], key[2 * i + 1], o0, o1, o2, o3);
     out[4 * i] = o0; out[4 * i + 1] = o1; out[4 * i + 2] = o2; out[4 * i + 3] = o3;
 }
+#endif // RTMI_LEAN_TU
