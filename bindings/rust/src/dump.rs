@@ -65,6 +65,14 @@ mod tests {
         }
     }
     #[test]
+    fn compositions_match_the_cpp_lowering() {
+        // list leaves (tie order), instanced primitives, a flipped subtree, a medium inside transforms
+        if let Some(want) = golden("compositions") {
+            let got = flat_scene_bytes(&lower::lower_world(&scenes::compositions(1)).unwrap());
+            assert!(got == want, "flat compositions differs from the C++ lowering");
+        }
+    }
+    #[test]
     fn final_scene_matches_the_cpp_lowering() {
         let earth = std::fs::read(format!("{}/../../earthmap.rgb8", env!("CARGO_MANIFEST_DIR"))).ok();
         if let (Some(want), Some(earth)) = (golden("final_scene"), earth) {

@@ -99,6 +99,50 @@ pub fn final_scene(seed: u64, corrected: bool, earth: (Vec<u8>, u32, u32)) -> Rc
     hittable_list(world)
 }
 
+/// The compositions the lowering accepts beyond the reference's own scenes, in one world (twin of `compositions` in
+/// tools/dump_flat_scene.py; golden: tests/golden/flat_compositions.bin.gz): a HittableList as a BVH child with exact ties
+/// inside (coincident spheres, coincident rects, a nested list), instanced primitives as BVH leaves and list members,
+/// FlipNormals around an inner BVHNode, a ConstantMedium inside Traslate(Rotate(..)).
+pub fn compositions(seed: u64) -> Rc<HittableDesc> {
+    let mut s = SceneStreams::new(seed);
+    let red = diffuse_light(solid_texture(4.0, 0.2, 0.2));
+    let green = diffuse_light(solid_texture(0.2, 4.0, 0.2));
+    let blue = diffuse_light(solid_texture(0.2, 0.2, 4.0));
+    let grey = lambertian(solid_texture(0.7, 0.7, 0.7));
+    let glass = dielectric(1.5);
+    let inner = hittable_list(vec![
+        traslate(cube([0.0, 0.0, -0.5], [1.0, 1.0, 0.5], grey.clone()), [1.0, 0.0, 0.0]),
+        flip_normals(sphere([1.5, 1.4, 0.0], 0.4, red.clone())),
+    ]);
+    let lst = hittable_list(vec![
+        sphere([0.0, 0.5, 0.0], 0.5, red),
+        sphere([0.0, 0.5, 0.0], 0.5, green.clone()),
+        rect(PLANE_XY, -2.0, 0.0, -1.0, 1.0, 0.0, blue),
+        rect(PLANE_XY, -2.0, 0.0, -1.0, 1.0, 0.0, green),
+        inner,
+    ]);
+    let mut sub_list = vec![
+        sphere([-3.0, 0.5, 1.0], 0.5, grey.clone()),
+        rotate(AXIS_Y, cube([-0.3, 0.0, -0.3], [0.3, 0.8, 0.3], grey.clone()), 30.0),
+        sphere([-3.0, 0.5, -1.0], 0.5, glass.clone()),
+    ];
+    let sub = bvh_new(&mut sub_list, 0.0, 1.0, &mut s.backend);
+    let mut objs = vec![
+        lst,
+        sphere([0.0, -100.0, 0.0], 100.0, grey.clone()),
+        sphere([3.0, 0.5, 0.0], 0.5, grey.clone()),
+        flip_normals(sub),
+        flip_normals(rect(PLANE_XY, -4.0, 0.0, 4.0, 3.0, -2.0, grey.clone())),
+        traslate(rotate(AXIS_Z, moving_sphere([0.0, 0.0, 0.0], [0.0, 0.3, 0.0], 0.0, 1.0, 0.3, grey), 20.0), [2.0, 2.0, 1.0]),
+    ];
+    let bvh = bvh_new(&mut objs, 0.0, 1.0, &mut s.backend);
+    hittable_list(vec![
+        bvh,
+        traslate(rotate(AXIS_Y, constant_medium(sphere([0.0, 0.0, 0.0], 1.0, glass), 0.5, solid_texture(0.9, 0.9, 0.9)), 25.0), [-1.5, 1.5, 2.0]),
+        sphere([0.0, 6.0, 0.0], 1.5, diffuse_light(solid_texture(4.0, 4.0, 4.0))),
+    ])
+}
+
 /// Camera literals of the #[test] drivers (tests/test.rs:741-752, 780-791, 819-830): (look_from, look_at, vfov);
 /// every driver uses view_up = (0,1,0), focus_dist = 10, aperture = 0.1, shutter [0,1], aspect = nx/ny (:47).
 pub fn camera_of(scene: &str) -> ([f64; 3], [f64; 3], f64) {

@@ -1,5 +1,6 @@
-"""tests/golden/flat_*.bin.gz are byte dumps of the C++ lowering (rt_host.cpp SceneBuilder) of cornell_box and
-final_scene (scene seed 1), written by tools/dump_flat_scene.py.  They exist for the Rust shim: bindings/rust/src/lower.rs
+"""tests/golden/flat_*.bin.gz are byte dumps of the C++ lowering (rt_host.cpp SceneBuilder) of cornell_box,
+final_scene (scene seed 1) and `compositions` (what the lowering accepts beyond the reference's own scenes: list leaves,
+instanced primitives, a flipped subtree, a medium inside transforms), written by tools/dump_flat_scene.py.  They exist for the Rust shim: bindings/rust/src/lower.rs
 mirrors that lowering function by function and cannot be compiled in this image; on a machine with cargo its output
 (`rtmi::dump::flat_scene_bytes`) must equal these bytes.  Here: the fixtures still match the current C++ lowering, are
 self-consistent, and the Rust sources reference them."""
@@ -49,8 +50,9 @@ def test_rust_sources_name_the_goldens():
     for f in ("lower.rs", "desc.rs", "scenes.rs", "dump.rs", "philox.rs", "lib.rs", "sys.rs"):
         assert os.path.exists(os.path.join(src, f)), f
     dump = open(os.path.join(src, "dump.rs")).read()
-    assert "RTMIFLT1" in dump and "flat_{}.bin" in dump
+    assert "RTMIFLT1" in dump and "flat_{}.bin" in dump and "scenes::compositions(1)" in dump
+    assert "pub fn compositions(seed: u64)" in open(os.path.join(src, "scenes.rs")).read()
     lower = open(os.path.join(src, "lower.rs")).read()
     for fn in ("fn push_prim", "fn lower_bvh", "fn build_alt_tree", "fn collapse_alt", "fn lower_item", "fn lower_world",
-               "fn contained", "fn true_bounds"):
+               "fn contained", "fn true_bounds", "fn lower_leaf", "fn lower_list_leaf", "fn list_subtree"):
         assert fn in lower, fn
