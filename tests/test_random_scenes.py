@@ -232,3 +232,29 @@ def test_list_as_bvh_leaf_matches_the_fp32_oracle(host, orc32):
         assert np.array_equal(got["linear"], ref["linear"]), flags
         assert np.array_equal(got["rgb8"].astype(np.int32), ref["rgb"]), flags
     orc32.free_all()
+
+
+@pytest.mark.gpu
+def test_compositions_scene_matches_the_fp32_oracle(host, orc32):
+    """The scene of tests/golden/flat_compositions.bin.gz (tools/dump_flat_scene.py: list leaves with ties, instanced
+    primitives, a flipped subtree, a medium inside Traslate(Rotate(..))) on the device: every kernel == the fp32 oracle."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dump_flat_scene as dfs
+
+    nx, ny, ns = 96, 64, 16
+    worlds, cams = [], []
+    for api in (host, orc32):
+        worlds.append(dfs.compositions(api, 1))
+        cams.append(api.Camera((0.5, 1.5, 7.0), (0.0, 0.8, 0.0), (0.0, 1.0, 0.0), 40.0, nx / ny, 0.05, 7.0, 0.0, 1.0))
+    sc = host.lower(worlds[0])
+    ref = orc32.render(cams[1], worlds[1], nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM)
+    assert float(ref["linear"].mean()) > 0.02
+    for flags in (0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_REF_TREE,
+                  abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL):
+        got = sc.render(cams[0], nx, ny, ns, seed=42, flags=flags, sig=True)
+        assert np.array_equal(got["sig"], ref["sig"]), flags
+        assert np.array_equal(got["linear"], ref["linear"]), flags
+        assert np.array_equal(got["rgb8"].astype(np.int32), ref["rgb"]), flags
+    orc32.free_all()
