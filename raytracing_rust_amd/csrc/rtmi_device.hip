@@ -64,6 +64,7 @@ struct rtmi_scene {
     int slots = 0;                  // CUs x 16: resident wavefronts the render kernels are launched with
     bool has_alt = false;           // some BVH item carries an alternative tree
     bool all_alt = false;           // every BVH item does (and there is one): the workgroup-cooperative kernel can run
+    uint32_t last_kernel = 0;       // RTMI_KERNEL_* of the last render enqueued on this handle (rtmi_stats.kernel)
     // scratch of the blocking host API (grow-only, so a host that renders frame after frame allocates once)
     rtmi_texel *texels = nullptr;
     size_t texel_count = 0;
@@ -623,6 +624,7 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     const size_t bcoop_lds = (size_t)RTMI_BLK_LDS_WORDS(RTMI_BLK_CAP) * sizeof(uint32_t);
     // (test knob bit 11: a stack so small that rounds are throttled all the time — room for 64 visits when it is full)
     if (bcoop) P.coop_cap = (p->flags & (1u << 11)) ? 3u * RTMI_BLK_THREADS + 64u : RTMI_BLK_CAP;
+    s->last_kernel = bcoop ? RTMI_KERNEL_BLOCK_COOP : coop ? RTMI_KERNEL_WAVE_COOP : async ? RTMI_KERNEL_ASYNC : RTMI_KERNEL_PERLANE;
     const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + (ext ? 0u : RTMI_RNG_RING_WORDS)) * sizeof(uint32_t);
     const uint32_t ntex = P.ntiles_local * 64u;
     uint32_t blocks_total = 0, chunks_total = 0;
@@ -711,7 +713,7 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
         }
         stats->samples = pix * p->ns;
         stats->tiles = P.ntiles_local; stats->chunks = chunks_total; stats->blocks = blocks_total;
-        stats->kernel = bcoop ? RTMI_KERNEL_BLOCK_COOP : coop ? RTMI_KERNEL_WAVE_COOP : async ? RTMI_KERNEL_ASYNC : RTMI_KERNEL_PERLANE;
+        stats->kernel = s->last_kernel;
         unsigned int st = 0; // this call's overflow word (the kernels have finished: ev[2] was waited for)
         HIP_TRY(hipMemcpy(&st, s->status, sizeof(st), hipMemcpyDeviceToHost));
         if (st != 0) {
@@ -851,8 +853,7 @@ static void fill_stats(rtmi_scene *s, const rtmi_render_params *p, rtmi_stats *s
         pix += (uint64_t)w * h;
     }
     stats->samples = pix * p->ns;
-    stats->tiles = nl; stats->chunks = 0; stats->blocks = 0; stats->kernel = 0;
-    (void)s;
+    stats->tiles = nl; stats->chunks = 0; stats->blocks = 0; stats->kernel = s->last_kernel;
 }
 
 // pinned host mirror of a texel buffer (grow-only)
@@ -1174,7 +1175,7 @@ extern "C" int rtmi_multi_render(rtmi_multi *m, const rtmi_camera *cam, const rt
             HIP_TRY(hipEventElapsedTime(&ms_all, m->scenes[i]->ev[0], m->scenes[i]->ev[2]));
             rtmi_stats one{};
             fill_stats(m->scenes[i], &params[i], &one, ms_r, ms_all);
-            stats->samples += one.samples; stats->tiles += one.tiles;
+            stats->samples += one.samples; stats->tiles += one.tiles; stats->kernel = one.kernel;
             if (one.render_ms > stats->render_ms) stats->render_ms = one.render_ms;
             if (one.kernel_ms > stats->kernel_ms) stats->kernel_ms = one.kernel_ms;
         }

@@ -100,6 +100,7 @@ def test_resident_scene_renders_like_rtmi_render(host, devices):
             res = sc.render_resident(cam, nx, ny, ns, seed=seed, flags=abi.RTMI_FLAG_FAST_CULL)
             assert np.array_equal(res["linear"], one["linear"]) and np.array_equal(res["rgb8"], one["rgb8"]), (k, devices)
             assert res["stats"]["samples"] == nx * ny * ns and res["stats"]["render_ms"] > 0
+            assert res["stats"]["kernel"] == one["stats"]["kernel"] == abi.RTMI_KERNEL_WAVE_COOP
             assert one["linear"].mean() > 0.01
         shot = sc.render_multi(cam, nx, ny, ns, devices, seed=seed, flags=abi.RTMI_FLAG_FAST_CULL)
         assert np.array_equal(shot["linear"], one["linear"])
