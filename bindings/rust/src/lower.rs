@@ -21,6 +21,7 @@ pub enum LowerError {
 
 const F32_MAX: f32 = 3.402_823_466_385_288_6e38;
 
+const ALT_PLAN_H: usize = 16; // height budgets the collapse plan is computed for (rt_host.hpp RTMI_ALT_PLAN_H)
 fn zero_item() -> RtmiItem {
     RtmiItem {
         kind: 0, first: 0, count: 0, flags: 0, xform_first: 0, xform_count: 0, medium_material: 0, neg_inv_density: 0.0,
@@ -253,11 +254,15 @@ pub struct SceneBuilder {
     mat_ids: HashMap<*const MaterialDesc, i32>,
     run_item: Option<usize>,
     alt_scratch: Vec<RtmiBvhNode>, // binary SAH tree of the item being lowered
+    alt_forest: Vec<f64>,          // plan_collapse: [binary node][height level][slots 0..4] cheapest collapse
+    alt_split: Vec<i8>,            // ... and the split that achieves it (slot 0: the node's own share-out)
+    alt_plan_levels: usize,        // 1 = planned without the height bound
+    alt_plan_height: usize,
 }
 
 impl SceneBuilder {
     pub fn new() -> Self {
-        SceneBuilder { out: FlatScene::new(), prim_box: Vec::new(), tex_ids: HashMap::new(), mat_ids: HashMap::new(), run_item: None, alt_scratch: Vec::new() }
+        SceneBuilder { out: FlatScene::new(), prim_box: Vec::new(), tex_ids: HashMap::new(), mat_ids: HashMap::new(), run_item: None, alt_scratch: Vec::new(), alt_forest: Vec::new(), alt_split: Vec::new(), alt_plan_levels: 1, alt_plan_height: 0 }
     }
 
     // ---- textures / materials: one record per distinct object (identity = Rc pointer) ------------------------
@@ -687,9 +692,91 @@ impl SceneBuilder {
         (id as i32, surrounding_box(&lb, &rb))
     }
 
-    /// Binary SAH tree -> 4-wide nodes: a node's children are its grandchildren where the child is an internal
-    /// node, the child itself where it is a leaf (rt_host.cpp collapse_alt).
-    fn collapse_alt(&mut self, r: i32, depth: u32) -> i32 {
+    /// Optimal collapse of the binary SAH tree into 4-wide nodes under a height bound (rt_host.cpp plan_collapse; the
+    /// dynamic programme of Ylitie, Karras, Laine 2017 for width 4): cost = summed box area of the 4-wide nodes; the
+    /// lowest tree within 2 % of the unconstrained optimum is taken.
+    ///   node[v][h]      = area(v) + min_{a=1..3} (forest[left][a][h-1] + forest[right][4-a][h-1])
+    ///   forest[v][j][h] = min(node[v][h], min_{a=1..j-1} (forest[left][a][h] + forest[right][j-a][h]))
+    fn plan_collapse(&mut self, root: i32) {
+        self.alt_plan_height = 0;
+        if root < 0 {
+            return;
+        }
+        const INF: f64 = 1e300;
+        for attempt in 0..2 {
+            let bounded = attempt == 0 && self.alt_scratch.len() <= 65536;
+            if attempt == 0 && !bounded {
+                continue;
+            }
+            let h_max: usize = if bounded { ALT_PLAN_H } else { 0 };
+            let levels = h_max + 1;
+            self.alt_plan_levels = levels;
+            self.alt_forest = vec![INF; self.alt_scratch.len() * levels * 5];
+            self.alt_split = vec![0i8; self.alt_scratch.len() * levels * 5];
+            // children before parents: the scratch tree is stored in preorder, so reverse index order does it
+            for v in (0..self.alt_scratch.len()).rev() {
+                let n = self.alt_scratch[v];
+                let at = |v: usize, h: usize, j: usize| (v * levels + h) * 5 + j;
+                let f = |forest: &Vec<f64>, c: i32, j: usize, h: usize| if c < 0 { 0.0 } else { forest[at(c as usize, h, j)] };
+                let mut ext = [0.0f64; 3];
+                for k in 0..3 {
+                    ext[k] = (n.lmax[k] as f64).max(n.rmax[k] as f64) - (n.lmin[k] as f64).min(n.rmin[k] as f64);
+                }
+                let mut area = 2.0 * (ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0]);
+                if !(area < 1e200) {
+                    area = 1e200; // unbounded leaf boxes: finite, and no inf * 0
+                }
+                for h in 0..=h_max {
+                    let mut best = INF;
+                    let mut best_a = 1i8;
+                    if !bounded || h > 0 {
+                        let hc = if bounded { h - 1 } else { 0 };
+                        for a in 1..=3usize {
+                            let c = f(&self.alt_forest, n.left, a, hc) + f(&self.alt_forest, n.right, 4 - a, hc);
+                            if c < best {
+                                best = c;
+                                best_a = a as i8;
+                            }
+                        }
+                    }
+                    let node = if best < INF { area + best } else { INF };
+                    self.alt_split[at(v, h, 0)] = best_a;
+                    self.alt_forest[at(v, h, 1)] = node;
+                    for j in 2..=4usize {
+                        let mut fj = node;
+                        let mut sp = 0i8;
+                        for a in 1..j {
+                            let c = f(&self.alt_forest, n.left, a, h) + f(&self.alt_forest, n.right, j - a, h);
+                            if c < fj {
+                                fj = c;
+                                sp = a as i8;
+                            }
+                        }
+                        self.alt_forest[at(v, h, j)] = fj;
+                        self.alt_split[at(v, h, j)] = sp;
+                    }
+                }
+            }
+            let root_at = |h: usize| ((root as usize) * levels + h) * 5 + 1;
+            let optimum = self.alt_forest[root_at(h_max)];
+            if bounded && !(optimum < INF) {
+                continue; // does not fit ALT_PLAN_H levels: plan without the bound
+            }
+            self.alt_plan_height = h_max;
+            if bounded {
+                for h in 1..=h_max {
+                    if self.alt_forest[root_at(h)] <= optimum * 1.02 {
+                        self.alt_plan_height = h;
+                        break;
+                    }
+                }
+            }
+            return;
+        }
+    }
+
+    /// Binary SAH tree (alt_scratch) -> 4-wide nodes along the plan of plan_collapse (rt_host.cpp collapse_alt).
+    fn collapse_alt(&mut self, r: i32, depth: u32, height: usize) -> i32 {
         if r < 0 {
             return r; // leaf
         }
@@ -699,23 +786,19 @@ impl SceneBuilder {
         let id = self.out.alt_nodes.len();
         self.out.alt_nodes.push(RtmiBvh4Node { minx: [0.0; 4], miny: [0.0; 4], minz: [0.0; 4], maxx: [0.0; 4], maxy: [0.0; 4], maxz: [0.0; 4], child: [0; 4], pad: [0; 4] });
         let b = self.alt_scratch[r as usize];
+        let bounded = self.alt_plan_levels > 1;
+        let hb = if bounded { height - 1 } else { 0 }; // height budget of the slots of this node
         let mut slots: Vec<(i32, [f32; 3], [f32; 3])> = Vec::new();
-        for (ch, mn, mx) in [(b.left, b.lmin, b.lmax), (b.right, b.rmin, b.rmax)] {
-            if ch >= 0 {
-                let g = self.alt_scratch[ch as usize];
-                slots.push((g.left, g.lmin, g.lmax));
-                slots.push((g.right, g.rmin, g.rmax));
-            } else {
-                slots.push((ch, mn, mx));
-            }
-        }
+        let a = self.split_of(r, if bounded { height } else { 0 }, 0);
+        self.emit_slots(b.left, b.lmin, b.lmax, a, hb, &mut slots);
+        self.emit_slots(b.right, b.rmin, b.rmax, 4 - a, hb, &mut slots);
         let mut me = RtmiBvh4Node { minx: [0.0; 4], miny: [0.0; 4], minz: [0.0; 4], maxx: [0.0; 4], maxy: [0.0; 4], maxz: [0.0; 4], child: [0; 4], pad: [0; 4] };
         for c in 0..4 {
             if c < slots.len() {
                 let (rf, mn, mx) = slots[c];
                 me.minx[c] = mn[0]; me.miny[c] = mn[1]; me.minz[c] = mn[2];
                 me.maxx[c] = mx[0]; me.maxy[c] = mx[1]; me.maxz[c] = mx[2];
-                me.child[c] = self.collapse_alt(rf, depth + 1);
+                me.child[c] = self.collapse_alt(rf, depth + 1, if bounded { height - 1 } else { 0 });
             } else {
                 // empty slot: a box no ray can hit
                 me.minx[c] = F32_MAX; me.miny[c] = F32_MAX; me.minz[c] = F32_MAX;
@@ -725,6 +808,24 @@ impl SceneBuilder {
         }
         self.out.alt_nodes[id] = me;
         id as i32
+    }
+    fn split_of(&self, v: i32, h: usize, j: usize) -> usize {
+        self.alt_split[((v as usize) * self.alt_plan_levels + h) * 5 + j] as usize
+    }
+    /// the descendants of `r` that fill at most `j` slots of the node being built (0 = `r` itself as a node)
+    fn emit_slots(&self, r: i32, mn: [f32; 3], mx: [f32; 3], j: usize, hb: usize, slots: &mut Vec<(i32, [f32; 3], [f32; 3])>) {
+        if r < 0 || j == 1 {
+            slots.push((r, mn, mx));
+            return;
+        }
+        let a = self.split_of(r, hb, j);
+        if a == 0 {
+            slots.push((r, mn, mx)); // cheaper as a node of its own
+            return;
+        }
+        let g = self.alt_scratch[r as usize];
+        self.emit_slots(g.left, g.lmin, g.lmax, a, hb, slots);
+        self.emit_slots(g.right, g.rmin, g.rmax, j - a, hb, slots);
     }
 
     /// one entry of the world list: [FlipNormals][ConstantMedium][Traslate/Rotate chain] geometry
@@ -807,7 +908,8 @@ impl SceneBuilder {
                         self.alt_scratch.clear();
                         let n = prims.len();
                         let (broot, _) = self.build_alt_tree(&mut prims, 0, n, 1, scale / 8192.0);
-                        it.alt_first = self.collapse_alt(broot, 1);
+                        self.plan_collapse(broot);
+                        it.alt_first = self.collapse_alt(broot, 1, self.alt_plan_height);
                     }
                 }
             }

@@ -1000,9 +1000,78 @@ int32_t SceneBuilder::build_alt_tree(std::vector<int> &prims, size_t lo, size_t 
     return id;
 }
 
-// Binary SAH tree (alt_scratch_) -> 4-wide nodes: a node's children are its grandchildren where the child is an
-// internal node, the child itself where it is a leaf.  Returns a child reference for the 4-wide tree.
-int32_t SceneBuilder::collapse_alt(int32_t ref, uint32_t depth) {
+// Optimal collapse of the binary SAH tree into 4-wide nodes (the dynamic programme of Ylitie, Karras, Laine 2017, for
+// width 4) under a HEIGHT bound: every 4-wide node costs one four-slot visit for every ray that enters its box, so the
+// cost of a collapse is the summed box area of its nodes (the leaves cost the same in every collapse); and the cooperative
+// traversal is bound by its longest chains, so among the collapses the lowest tree whose cost is within 2 % of the
+// unconstrained optimum is taken.  For a binary node v and a height budget h (a leaf slot has height 0)
+//   node[v][h]      = area(v) + min_{a = 1..3} (forest[left][a][h-1] + forest[right][4 - a][h-1])   v becomes a node
+//   forest[v][j][h] = min(node[v][h], min_{a = 1..j-1} (forest[left][a][h] + forest[right][j - a][h]))  <= j slots
+// with forest[leaf][j][h] = 0, forest[v][1][h] = node[v][h], node[v][0] = infinity.  The fixed "grandchildren" rule it
+// replaces left 37 % of the nodes with two children (3.08 per node; now 3.5).
+void SceneBuilder::plan_collapse(int32_t root) {
+    alt_plan_height_ = 0;
+    if (root < 0) return;
+    const double inf = 1e300;
+    // bounded = with the height dimension (heights 0..H); otherwise one level that stands for "any height" — for trees too
+    // large for the table (17 x 5 doubles per binary node) or too unbalanced for H
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool bounded = attempt == 0 && alt_scratch_.size() <= 65536;
+        if (attempt == 0 && !bounded) continue;
+        const int H = bounded ? RTMI_ALT_PLAN_H : 0;
+        alt_plan_levels_ = H + 1;
+        alt_forest_.assign(alt_scratch_.size() * (size_t)alt_plan_levels_ * 5, inf);
+        alt_split_.assign(alt_scratch_.size() * (size_t)alt_plan_levels_ * 5, 0);
+        auto at = [&](int32_t v, int h, int j) { return ((size_t)v * (size_t)alt_plan_levels_ + (size_t)h) * 5 + (size_t)j; };
+        std::function<void(int32_t)> go = [&](int32_t v) {
+            const rtmi_bvh_node &n = alt_scratch_[(size_t)v];
+            if (n.left >= 0) go(n.left);
+            if (n.right >= 0) go(n.right);
+            auto F = [&](int32_t c, int j, int h) { return c < 0 ? 0.0 : alt_forest_[at(c, h, j)]; };
+            double mn[3], mx[3];
+            for (int k = 0; k < 3; k++) { mn[k] = std::fmin((double)n.lmin[k], (double)n.rmin[k]); mx[k] = std::fmax((double)n.lmax[k], (double)n.rmax[k]); }
+            const double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+            double area = 2.0 * (dx * dy + dy * dz + dz * dx);
+            if (!(area < 1e200)) area = 1e200; // unbounded leaf boxes (Rect, MovingSphere: +-FLT_MAX): finite, and no inf * 0
+            for (int h = 0; h <= H; h++) {
+                double best = inf;
+                int best_a = 1;
+                if (!bounded || h > 0)
+                    for (int a = 1; a <= 3; a++) {
+                        const double c = F(n.left, a, bounded ? h - 1 : 0) + F(n.right, 4 - a, bounded ? h - 1 : 0);
+                        if (c < best) { best = c; best_a = a; }
+                    }
+                const double node = best < inf ? area + best : inf;
+                alt_split_[at(v, h, 0)] = (int8_t)best_a; // slot 0 of the table: how this node, as a node, shares its four slots
+                alt_forest_[at(v, h, 1)] = node;
+                for (int j = 2; j <= 4; j++) {
+                    double f = node;
+                    int sp = 0;
+                    for (int a = 1; a < j; a++) {
+                        const double c = F(n.left, a, h) + F(n.right, j - a, h);
+                        if (c < f) { f = c; sp = a; }
+                    }
+                    alt_forest_[at(v, h, j)] = f;
+                    alt_split_[at(v, h, j)] = (int8_t)sp;
+                }
+            }
+        };
+        go(root);
+        const double optimum = alt_forest_[at(root, H, 1)];
+        if (bounded && !(optimum < inf)) continue; // does not fit H levels: plan without the bound
+        alt_plan_height_ = H;
+        // (final_scene: the 400 cubes reach the optimum at height 5, the lowest possible; the 1000 spheres cost 1.002 x
+        // the optimum at height 6, their lowest, and reach it at 7)
+        if (bounded)
+            for (int h = 1; h <= H; h++)
+                if (alt_forest_[at(root, h, 1)] <= optimum * 1.02) { alt_plan_height_ = h; break; }
+        return;
+    }
+}
+
+// Binary SAH tree (alt_scratch_) -> 4-wide nodes along the plan of plan_collapse().  Returns a child reference for the
+// 4-wide tree.
+int32_t SceneBuilder::collapse_alt(int32_t ref, uint32_t depth, int height) {
     if (ref < 0) return ref; // leaf
     if (depth > out.alt_max_depth) out.alt_max_depth = depth;
     const int32_t id = (int32_t)out.alt_nodes.size();
@@ -1015,16 +1084,24 @@ int32_t SceneBuilder::collapse_alt(int32_t ref, uint32_t depth) {
         for (int k = 0; k < 3; k++) { sl.mn[k] = mn[k]; sl.mx[k] = mx[k]; }
         slots.push_back(sl);
     };
-    const int32_t ch[2] = {b.left, b.right};
-    const float *cmn[2] = {b.lmin, b.rmin}, *cmx[2] = {b.lmax, b.rmax};
-    for (int c = 0; c < 2; c++) {
-        if (ch[c] >= 0) {
-            const rtmi_bvh_node g = alt_scratch_[(size_t)ch[c]];
-            add(g.left, g.lmin, g.lmax);
-            add(g.right, g.rmin, g.rmax);
-        } else {
-            add(ch[c], cmn[c], cmx[c]);
-        }
+    // Which descendants of `ref` become the (up to four) children of this node is decided by plan_collapse(): the
+    // choice that minimises the summed box area of all 4-wide nodes of the subtree (each node costs one four-slot visit
+    // for every ray that enters its box) — see there.
+    const bool bounded = alt_plan_levels_ > 1;
+    const int hb = bounded ? height - 1 : 0; // height budget of the slots of this node
+    auto split_of = [&](int32_t v, int h, int j) { return (int)alt_split_[((size_t)v * (size_t)alt_plan_levels_ + (size_t)h) * 5 + (size_t)j]; };
+    std::function<void(int32_t, const float *, const float *, int)> emit = [&](int32_t r, const float *mn, const float *mx, int j) {
+        if (r < 0 || j == 1) { add(r, mn, mx); return; }
+        const int a = split_of(r, hb, j);
+        if (a == 0) { add(r, mn, mx); return; } // cheaper as a node of its own
+        const rtmi_bvh_node g = alt_scratch_[(size_t)r];
+        emit(g.left, g.lmin, g.lmax, a);
+        emit(g.right, g.rmin, g.rmax, j - a);
+    };
+    {
+        const int a = split_of(ref, bounded ? height : 0, 0);
+        emit(b.left, b.lmin, b.lmax, a);
+        emit(b.right, b.rmin, b.rmax, 4 - a);
     }
     rtmi_bvh4_node me{};
     const float big = 3.40282346638528859811704183484516925e+38f;
@@ -1032,7 +1109,7 @@ int32_t SceneBuilder::collapse_alt(int32_t ref, uint32_t depth) {
         if (c < (int)slots.size()) {
             me.minx[c] = slots[c].mn[0]; me.miny[c] = slots[c].mn[1]; me.minz[c] = slots[c].mn[2];
             me.maxx[c] = slots[c].mx[0]; me.maxy[c] = slots[c].mx[1]; me.maxz[c] = slots[c].mx[2];
-            me.child[c] = collapse_alt(slots[c].ref, depth + 1);
+            me.child[c] = collapse_alt(slots[c].ref, depth + 1, height - 1);
         } else { // empty slot: a box no ray can hit
             me.minx[c] = me.miny[c] = me.minz[c] = big;
             me.maxx[c] = me.maxy[c] = me.maxz[c] = -big;
@@ -1109,7 +1186,8 @@ void SceneBuilder::lower_item(const Hittable &top) {
                 AABB rootbox(Vec3(0, 0, 0), Vec3(0, 0, 0));
                 alt_scratch_.clear();
                 const int32_t broot = build_alt_tree(prims, 0, prims.size(), 1, scale / 8192.0, &rootbox);
-                it.alt_first = collapse_alt(broot, 1);
+                plan_collapse(broot);
+                it.alt_first = collapse_alt(broot, 1, alt_plan_height_);
             }
         }
     } else if (auto list = dynamic_cast<const HittableList *>(h)) {

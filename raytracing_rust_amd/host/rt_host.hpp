@@ -367,7 +367,13 @@ class SceneBuilder {
     int32_t lower_list_leaf(const HittableList &l, const BVHNode &holder, uint32_t depth, bool flip, bool force_moving, double pad,
                             bool unbounded_leaves, AABB &box_out);
     int32_t build_alt_tree(std::vector<int> &prims, size_t lo, size_t hi, uint32_t depth, double pad, AABB *box_out);
-    int32_t collapse_alt(int32_t ref, uint32_t depth); // binary scratch tree -> 4-wide nodes in out.alt_nodes
+#define RTMI_ALT_PLAN_H 16 /* height budgets the collapse plan is computed for */
+    std::vector<double> alt_forest_; // [binary node][height level][slots 0..4]: cost of the cheapest collapse (plan_collapse)
+    std::vector<int8_t> alt_split_;  // ... and the split that achieves it (slot 0: the node's own share-out)
+    int alt_plan_levels_ = 1;        // 1 = planned without the height bound
+    int alt_plan_height_ = 0;
+    void plan_collapse(int32_t root);
+    int32_t collapse_alt(int32_t ref, uint32_t depth, int height); // binary scratch tree -> 4-wide nodes in out.alt_nodes
     std::vector<rtmi_bvh_node> alt_scratch_;            // binary SAH tree being built for the current item
     int run_item_ = -1; // index of the item that collects the current run of plain top-level primitives
     std::map<const Texture *, int> tex_ids_;

@@ -54,5 +54,5 @@ def test_rust_sources_name_the_goldens():
     assert "pub fn compositions(seed: u64)" in open(os.path.join(src, "scenes.rs")).read()
     lower = open(os.path.join(src, "lower.rs")).read()
     for fn in ("fn push_prim", "fn lower_bvh", "fn build_alt_tree", "fn collapse_alt", "fn lower_item", "fn lower_world",
-               "fn contained", "fn true_bounds", "fn lower_leaf", "fn lower_list_leaf", "fn list_subtree"):
+               "fn contained", "fn true_bounds", "fn lower_leaf", "fn lower_list_leaf", "fn list_subtree", "fn plan_collapse", "fn emit_slots"):
         assert fn in lower, fn
