@@ -175,8 +175,8 @@ def test_scene_validation_walks_the_trees(host):
     alt[k0].child[slot] = d.n_alt_nodes + 5
     rc, msg = _create_rc(d)
     assert rc == 1 and "out of range" in msg
-    alt[k0].child[slot] = C.c_int32(0x80000000 | (abi.PRIM_SPHERE << 28) | 0).value  # primitive 0 is a cube here
-    assert d.prim_meta[0].type == abi.PRIM_CUBE
+    cube0 = [i for i in range(d.n_prims) if d.prim_meta[i].type == abi.PRIM_CUBE][0]  # (the first primitives are the spheres that travel with the BVH)
+    alt[k0].child[slot] = C.c_int32(0x80000000 | (abi.PRIM_SPHERE << 28) | cube0).value  # a sphere leaf naming a cube
     rc, msg = _create_rc(d)
     assert rc == 1 and "type mismatch" in msg
     alt[k0].child[slot] = C.c_int32(0x80000000 | (abi.PRIM_CUBE << 28) | (d.n_prims + 7)).value
