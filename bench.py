@@ -193,7 +193,7 @@ def launch_ranks(n, argv, timeout_s):
     return rc
 
 
-def abi_multi_leg(devices, scene_name, nx, ny, ns, flags, steps, ppm_path, compare_single=False):
+def abi_multi_leg(devices, scene_name, nx, ny, ns, flags, steps, ppm_path, compare_single=False, force_rccl=True):
     """The path a host's Camera::render binds for create_image (tests/test.rs:55-85) with a device list: ONE persistent
     handle (rtmi_multi_create), then whole-image renders from it.  Reports, for the same handle, what creating it
     costs, the first call (which allocates the per-sample buffers) and the steady state — each as wall clock from the
@@ -220,7 +220,11 @@ def abi_multi_leg(devices, scene_name, nx, ny, ns, flags, steps, ppm_path, compa
         return t1 - t0, t2 - t0, r
 
     # cold: the first create of this process also pays the HIP context of every device and, for distinct devices, the
-    # RCCL communicator set (cached per device list for the process lifetime); warm: what a host pays per handle
+    # RCCL communicator set (dlopen + ncclCommInitAll; the set goes back to a per-device-list pool at destroy and the
+    # next handle takes it over); warm: what a host pays per handle.  A one-entry list gets a one-rank communicator
+    # too here (RTMI_FORCE_RCCL), so that the leg runs the same grouped ncclGather at N = 1 as at N = 8.
+    if force_rccl:
+        os.environ["RTMI_FORCE_RCCL"] = "1"
     t = time.perf_counter()
     sc.upload_multi(devices)
     t_create_cold = time.perf_counter() - t
@@ -228,6 +232,10 @@ def abi_multi_leg(devices, scene_name, nx, ny, ns, flags, steps, ppm_path, compa
     t = time.perf_counter()
     sc.upload_multi(devices)
     t_create = time.perf_counter() - t
+    collective = sc.multi_collective()
+    t = time.perf_counter()
+    sc.prepare_resident(nx, ny, ns, **kw)  # the per-sample radiance buffers (12 B x pixels x spp per device) alone
+    t_prepare = time.perf_counter() - t
     call1, first, r = to_ppm(lambda: sc.render_resident(cam, nx, ny, ns, out=out, **kw))
     calls, walls, kern = [], [], []
     for _ in range(steps):
@@ -239,7 +247,8 @@ def abi_multi_leg(devices, scene_name, nx, ny, ns, flags, steps, ppm_path, compa
     t_destroy = time.perf_counter() - t
     res = {
         "entry_points": "rtmi_multi_create / rtmi_multi_render / rtmi_multi_destroy", "devices": list(devices),
-        "workload": "%s %dx%dx%dspp" % (scene_name, nx, ny, ns), "steps": steps,
+        "workload": "%s %dx%dx%dspp" % (scene_name, nx, ny, ns), "steps": steps, "collective": collective,
+        "prepare_s": round(t_prepare, 4),
         "lower_s": round(t_lower, 4), "create_first_in_process_s": round(t_create_cold, 4), "create_s": round(t_create, 4),
         "destroy_s": round(t_destroy, 4),
         "first_call_s": round(call1, 4), "first_call_to_ppm_s": round(first, 4),
@@ -247,7 +256,7 @@ def abi_multi_leg(devices, scene_name, nx, ny, ns, flags, steps, ppm_path, compa
         "steady_to_ppm_min_s": round(float(np.min(walls)), 4),
         "steady_kernel_ms_slowest_device": round(float(np.mean(kern)), 3),
         "steady_msamples_per_s": round(float(nx) * ny * ns / float(np.mean(calls)) / 1e6, 2),
-        "one_shot_fixed_cost_s": round(t_create + (call1 - float(np.mean(calls))) + t_destroy, 4),
+        "one_shot_fixed_cost_s": round(t_create + t_prepare + (call1 - float(np.mean(calls))) + t_destroy, 4),
         "checks": checks,
     }
     if compare_single:
@@ -265,6 +274,39 @@ def abi_multi_leg(devices, scene_name, nx, ny, ns, flags, steps, ppm_path, compa
                                           "image_equal": bool(np.array_equal(r1["rgb8"], r["rgb8"]))}
     host.free_all()
     return res
+
+
+def cold_one_shot(scene_name, nx, ny, ns, flags, ppm_path, spawned_at):
+    """The reference's usage model — one render per process (tests/test.rs:802-838: set_camera, final_scene(),
+    create_image, write) — through the one-shot entry point: a FRESH process builds the scene, lowers it, calls
+    rtmi_render_multi on [0] once (upload + the 25 GB per-sample buffer + kernels + gather + D2H + un-tiling inside) and
+    writes the P3 file.  `spawned_at` = the parent's time.time() just before it started this process, so that
+    cold_wall_clock_to_ppm_s includes the interpreter start and the imports (numpy, the two libraries; no torch)."""
+    t_main = time.time()
+    import numpy as np  # noqa: F401
+
+    from raytracing_rust_amd import Host, scenes, write_ppm
+
+    t_imp = time.time()
+    host = Host()
+    cam, world = scenes.build(host, scene_name, nx, ny, seed=1)
+    sc = host.lower(world)
+    t_scene = time.time()
+    r = sc.render_multi(cam, nx, ny, ns, [0], seed=42, flags=flags)
+    t_render = time.time()
+    write_ppm(ppm_path, r["rgb8"], 3)
+    t_ppm = time.time()
+    return {
+        "entry_point": "rtmi_render_multi (one-shot: create + render + destroy) on [0], fresh process, first GPU call of it",
+        "workload": "%s %dx%dx%dspp" % (scene_name, nx, ny, ns),
+        "cold_wall_clock_to_ppm_s": round(t_ppm - spawned_at, 4),
+        "process_start_and_imports_s": round(t_imp - spawned_at, 4), "of_which_interpreter_start_s": round(t_main - spawned_at, 4),
+        "scene_build_and_lower_s": round(t_scene - t_imp, 4),
+        "render_call_s": round(t_render - t_scene, 4), "kernel_ms": round(r["stats"]["kernel_ms"], 3),
+        "call_minus_kernels_s": round(t_render - t_scene - r["stats"]["kernel_ms"] * 1e-3, 4),
+        "ppm_write_s": round(t_ppm - t_render, 4),
+        "checks": {"ppm_bytes": os.path.getsize(ppm_path), "samples": r["stats"]["samples"]},
+    }
 
 
 def load_profile_summary(path, workload):
@@ -292,23 +334,29 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=16)
-    ap.add_argument("--cpu-spp", type=int, default=144)
+    ap.add_argument("--cpu-spp", type=int, default=320)  # x 16 rows x 1920 px = 9.8 M samples: about 30 s of one core
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo only to rehearse N > 1 on a box with "
                          "fewer GPUs than ranks (ranks share GPUs, the gather goes through host memory)")
+    ap.add_argument("--no-collective-at-1", action="store_true",
+                    help="N = 1: do not make a one-rank process group (by default the single rank initialises the backend and "
+                         "every step's gather is a real torch.distributed.gather on it, so the N = 1 line has crossed RCCL)")
     ap.add_argument("--ppm-out", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "rtmi_bench.ppm"))
     ap.add_argument("--sample-buffer-mb", type=int, default=0, help="per-sample buffer budget (0 = library default)")
     ap.add_argument("--profile-json", default=os.path.join(ROOT, "profiles", "pmc_summary.json"))
     ap.add_argument("--cpu-allcore-procs", type=int, default=-1,
                     help="workers of the all-core CPU sample (-1 = every core this process may use: os.cpu_count() "
                          "unless the scheduler affinity or the cgroup quota is smaller; 0 = skip)")
-    ap.add_argument("--cpu-allcore-seconds", type=float, default=12.0, help="wall-clock target of the all-core sample")
+    ap.add_argument("--cpu-allcore-seconds", type=float, default=20.0, help="wall-clock target of the all-core sample")
     ap.add_argument("--abi-multi", default="auto",
                     help="devices of the persistent C-ABI handle leg (rtmi_multi_*): 'auto' = [0] at N = 1 and all N "
                          "devices (in a child process of rank 0, after the ranks have finished) at N > 1; 'off'; or a "
                          "comma-separated device list")
     ap.add_argument("--abi-multi-child", default="", help=argparse.SUPPRESS)  # internal: run only the handle leg
+    ap.add_argument("--cold-child", type=float, default=0.0, help=argparse.SUPPRESS)  # internal: the cold one-shot leg
+    ap.add_argument("--no-cold-start", action="store_true",
+                    help="N = 1: skip the cold one-shot leg (a fresh child process: start -> scene -> rtmi_render_multi -> PPM)")
     ap.add_argument("--abi-multi-steps", type=int, default=3)
     ap.add_argument("--abi-multi-timeout", type=int, default=240, help="seconds the N > 1 child may take")
     ap.add_argument("--no-baseline-config", action="store_true",
@@ -326,6 +374,25 @@ def main():
         print(json.dumps(abi_multi_leg(devs, args.scene, args.nx, args.ny, args.spp, args.flags, args.abi_multi_steps,
                                        args.ppm_out + ".multi")), flush=True)
         return
+
+    if args.cold_child:
+        print(json.dumps(cold_one_shot(args.scene, args.nx, args.ny, args.spp, args.flags, args.ppm_out + ".cold", args.cold_child)),
+              flush=True)
+        return
+
+    # ---- N = 1: the cold one-shot, in a fresh child BEFORE this process touches the GPU (and before the CPU legs load the host)
+    cold = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1 and not args.no_cold_start:
+        cmd = [sys.executable, os.path.abspath(__file__), "--scene", args.scene, "--nx", str(args.nx), "--ny", str(args.ny),
+               "--spp", str(args.spp), "--flags", str(args.flags), "--ppm-out", args.ppm_out]
+        try:
+            cp = subprocess.run(cmd + ["--cold-child", repr(time.time())], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            cold = (json.loads(cp.stdout.decode().strip().splitlines()[-1]) if cp.returncode == 0 else
+                    {"error": "child exited with code %d" % cp.returncode, "stderr_tail": cp.stderr.decode(errors="replace")[-600:]})
+        except subprocess.TimeoutExpired:
+            cold = {"error": "child exceeded 240 s and was killed"}
+        except Exception as e:
+            cold = {"error": repr(e)}
 
     allcore = None
     host_cores, usable_cores = host_core_counts()
@@ -354,9 +421,22 @@ def main():
                          "GPUs)" % (args.gpus, env_world, torch.cuda.device_count()))
     if not torch.cuda.is_available() or abi.load_rtmi().rtmi_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the rtmi render path has no CPU fallback")
-    rank, world, local_rank = rdist.init_process_group(args.backend)
+    collective_note = None
+    try:
+        rank, world, local_rank = rdist.init_process_group(args.backend, collective_at_1=not args.no_collective_at_1)
+    except Exception as e:  # a one-rank group that cannot be made must not cost the headline line
+        if env_world > 1:
+            raise
+        collective_note = "one-rank process group failed (%r): no collective ran" % (e,)
+        rank, world, local_rank = rdist.env_rank_world()
     if world > 1:
         world = dist.get_world_size()  # the ranks the backend actually connected
+    # what the gather of a step really is in this process
+    if dist.is_initialized():
+        collective = "%s: torch.distributed.gather on a %d-rank process group" % (
+            "RCCL" if args.backend == "nccl" else "gloo rehearsal", dist.get_world_size())
+    else:
+        collective = "none (single rank, no process group%s)" % ("" if collective_note is None else "; " + collective_note)
     if args.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -375,7 +455,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -448,7 +528,7 @@ def main():
         scene.check_status()
         fence()
 
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()  # the ranks are done; rank 0 goes on alone
     if rank != 0:
         return
@@ -500,7 +580,7 @@ def main():
             "workload": workload,
             "per_gpu": "%dx%dx%dspp-equivalent (tiles t %% %d == rank)" % (nx, ny, args.spp, world),
             "scene_seed": 1, "render_seed": 42, "max_depth": 50, "t_min": 0.001,
-            "parallelism": "tile-interleave x%d + one gather (%s)" % (world, "RCCL" if args.backend == "nccl" else "gloo rehearsal"),
+            "parallelism": "tile-interleave x%d + one gather (%s)" % (world, collective),
             "flags": args.flags,
         },
         "kernel_ms_avg": round(kernel_ms_avg, 3),
@@ -514,6 +594,9 @@ def main():
         out["baseline_config"] = baseline_cfg
     if abi_multi is not None:
         out["abi_multi"] = abi_multi
+    if cold is not None:
+        out["cold_start"] = cold
+        out["cold_wall_clock_to_ppm_s"] = cold.get("cold_wall_clock_to_ppm_s")
 
     # ---- roofline + cpu baseline (rank 0).  Operation counts come from a small pass of the instrumented oracle;
     # the TIMED baseline is the uninstrumented -march=native build (N = 1 only).

@@ -209,6 +209,11 @@ impl DeviceScene {
     pub fn prepare(&mut self, p: &RtmiRenderParams) -> Result<(), RtmiError> {
         check(unsafe { rtmi_multi_prepare(self.raw, p) })
     }
+    /// What brings the tiles of a render together: 0 nothing to exchange (one device), 1 device-to-device copies
+    /// (a device listed twice), 2 one grouped ncclGather over xGMI (distinct devices; RTMI_FORCE_RCCL=1 for one).
+    pub fn collective(&self) -> i32 {
+        unsafe { rtmi_multi_collective(self.raw) }
+    }
     /// Blocking whole-image render over all devices of the handle (tile_rank / tile_world = 0 / 1).
     pub fn render(&mut self, cam: &RtmiCamera, p: &RtmiRenderParams) -> Result<Image, RtmiError> {
         let (nx, ny) = (p.nx as usize, p.ny as usize);

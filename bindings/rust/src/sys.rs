@@ -263,6 +263,8 @@ extern "C" {
     pub fn rtmi_last_error() -> *const c_char;
     pub fn rtmi_scene_create(desc: *const RtmiSceneDesc, device: c_int, out: *mut *mut RtmiScene) -> c_int;
     pub fn rtmi_scene_destroy(scene: *mut RtmiScene);
+    /// frees the per-sample buffers that destroyed handles left parked (one per device) for their successors
+    pub fn rtmi_release_cached();
     pub fn rtmi_local_tiles(p: *const RtmiRenderParams) -> u32;
     pub fn rtmi_render_prepare(scene: *mut RtmiScene, p: *const RtmiRenderParams) -> c_int;
     pub fn rtmi_render_device(
@@ -295,6 +297,8 @@ extern "C" {
         stats: *mut RtmiStats,
     ) -> c_int;
     pub fn rtmi_multi_destroy(m: *mut RtmiMulti);
+    /// RTMI_COLLECTIVE_*: 0 none (one device), 1 peer copies (a device listed twice), 2 one grouped ncclGather
+    pub fn rtmi_multi_collective(m: *const RtmiMulti) -> c_int;
     pub fn rtmi_render(
         scene: *mut RtmiScene,
         cam: *const RtmiCamera,

@@ -298,7 +298,14 @@ const char *rtmi_last_error(void);
 
 /* Copies the description to `device` (hipMemcpy). */
 int rtmi_scene_create(const rtmi_scene_desc *desc, int device, rtmi_scene **out);
+/* Frees the handle.  Its per-sample radiance buffer (the one large allocation, up to 45 GiB) is PARKED instead of freed:
+ * one buffer per device outlives its handle, and the next handle on that device (also inside rtmi_multi_* and the
+ * one-shot rtmi_render_multi) takes it over when it is large enough — hosts that render one image per handle, the
+ * reference's usage model (tests/test.rs:802-838), then do not pay a multi-GB hipMalloc per image, which on this
+ * stack now and then takes seconds right after a hipFree of the same size.  rtmi_release_cached()
+ * returns the parked memory of all devices to the system. */
 void rtmi_scene_destroy(rtmi_scene *scene);
+void rtmi_release_cached(void);
 
 /* Number of tiles / texels in the tile-packed local framebuffer of this call:
  * texel index = local_tile * 64 + (ly * 8 + lx), local_tile = tile / tile_world,
@@ -336,9 +343,21 @@ int rtmi_scene_status(rtmi_scene *scene, uint32_t *overflows);
  * all devices concurrently; the gather onto devices[0] is one ncclGather over xGMI (rccl.h) when the listed devices
  * are distinct, plain device-to-device copies when a device is listed more than once (single-GPU rehearsal: RCCL
  * cannot put two ranks on one device).  The image is bit-identical to rtmi_render's for any device list.
+ * A communicator set belongs to ONE handle while that handle lives (RCCL lets one thread at a time enqueue on a
+ * communicator): it is checked out of a per-device-list pool at create — made with ncclCommInitAll when the pool has
+ * none free — and handed back at destroy, so two live handles on the same device list render concurrently on their
+ * own communicators and one-shot calls reuse a set instead of initialising one per image.
+ * A one-entry device list needs no exchange and loads no RCCL; with RTMI_FORCE_RCCL=1 in the environment at create
+ * it gets a one-rank communicator as well and the render runs the same grouped ncclGather (the way to execute the
+ * whole collective path on a single GPU).  rtmi_multi_collective() says which exchange a handle uses.
  * stats (optional): kernel_ms / render_ms = the slowest device's, samples = all devices'.
  * params: tile_rank / tile_world must be 0 / 1; PATH_SIG and PROFILE are single-device diagnostics (rejected). */
 typedef struct rtmi_multi rtmi_multi;
+enum { RTMI_COLLECTIVE_NONE = 0,      /* one device, framebuffer copied on the device */
+       RTMI_COLLECTIVE_PEER_COPY = 1, /* a device listed more than once: hipMemcpyPeerAsync per rank */
+       RTMI_COLLECTIVE_RCCL = 2 };    /* one grouped ncclGather onto devices[0] */
+/* which exchange rtmi_multi_render of this handle performs (RTMI_COLLECTIVE_*; -1 for NULL) */
+int rtmi_multi_collective(const rtmi_multi *m);
 int rtmi_multi_create(const rtmi_scene_desc *desc, const int *devices, uint32_t n_devices, rtmi_multi **out);
 /* optional: allocate the per-sample buffers for renders with these params on every device now (idempotent) */
 int rtmi_multi_prepare(rtmi_multi *m, const rtmi_render_params *params);

@@ -10,6 +10,6 @@ The package holds only what the hot path needs:
 Importing the package does not need a GPU; rendering does, and fails loudly without one.
 """
 from . import abi, scenes  # noqa: F401
-from .host import Host, HostError, Panic, Unsupported, Scene, default_params, ppm_p3, write_ppm  # noqa: F401
+from .host import Host, HostError, Panic, Unsupported, Scene, default_params, ppm_p3, release_cached, write_ppm  # noqa: F401
 
-__all__ = ["Host", "HostError", "Panic", "Unsupported", "Scene", "default_params", "ppm_p3", "write_ppm", "abi", "scenes"]
+__all__ = ["Host", "HostError", "Panic", "Unsupported", "Scene", "default_params", "ppm_p3", "release_cached", "write_ppm", "abi", "scenes"]

@@ -24,6 +24,7 @@ RTMI_FLAG_SKY = 32
 RTMI_FLAG_REF_TREE = 64
 RTMI_FLAG_BLOCK_COOP = 32768
 RTMI_SAMPLE_SLOT_BYTES = 12  # per-sample radiance buffer: three fp32 per finished path
+RTMI_COLLECTIVE_NONE, RTMI_COLLECTIVE_PEER_COPY, RTMI_COLLECTIVE_RCCL = 0, 1, 2
 RTMI_KERNEL_PERLANE, RTMI_KERNEL_WAVE_COOP, RTMI_KERNEL_ASYNC, RTMI_KERNEL_BLOCK_COOP = 0, 1, 2, 3
 RTMI_FLAG_FACE_FORWARD = 128
 RTMI_FLAG_UV_BOOK = 4096
@@ -126,9 +127,9 @@ class Stats(C.Structure):
 
 
 # every entry point include/rtmi.h declares (tests check that the library exports them all)
-RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_local_tiles",
+RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_release_cached", "rtmi_local_tiles",
                 "rtmi_render_prepare", "rtmi_render_device", "rtmi_scene_status", "rtmi_render", "rtmi_render_multi", "rtmi_multi_create",
-                "rtmi_multi_prepare", "rtmi_multi_render", "rtmi_multi_destroy", "rtmi_partial_image", "rtmi_untile",
+                "rtmi_multi_prepare", "rtmi_multi_render", "rtmi_multi_destroy", "rtmi_multi_collective", "rtmi_partial_image", "rtmi_untile",
                 "rtmi_ppm_p3", "rtmi_write_ppm", "rtmi_probe_math", "rtmi_probe_philox", "rtmi_probe_xform"]
 
 _rtmi = None
@@ -151,6 +152,8 @@ def load_rtmi():
     lib.rtmi_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(vp)]
     lib.rtmi_scene_destroy.restype = None
     lib.rtmi_scene_destroy.argtypes = [vp]
+    lib.rtmi_release_cached.restype = None
+    lib.rtmi_release_cached.argtypes = []
     lib.rtmi_local_tiles.restype = C.c_uint32
     lib.rtmi_local_tiles.argtypes = [C.POINTER(RenderParams)]
     lib.rtmi_render_device.restype = C.c_int
@@ -170,6 +173,8 @@ def load_rtmi():
     lib.rtmi_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     lib.rtmi_multi_destroy.restype = None
     lib.rtmi_multi_destroy.argtypes = [vp]
+    lib.rtmi_multi_collective.restype = C.c_int
+    lib.rtmi_multi_collective.argtypes = [vp]
     lib.rtmi_render.restype = C.c_int
     lib.rtmi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
     lib.rtmi_partial_image.restype = C.c_int
@@ -243,6 +248,7 @@ def load_host():
         "rth_partial_image": (i, [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(C.c_uint32)]),
         "rth_upload_multi": (i, [vp, C.POINTER(C.c_int), u32]),
         "rth_multi_free": (i, [vp]),
+        "rth_multi_collective": (i, [vp]),
         "rth_multi_prepare": (i, [vp, C.POINTER(RenderParams)]),
         "rth_multi_render": (i, [vp, vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]),
         "rth_camera_render": (i, [vp, vp, u32, u32, u32, u64, u32, i, vp, vp, C.POINTER(Stats)]),

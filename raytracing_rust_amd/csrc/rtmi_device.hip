@@ -20,6 +20,7 @@
 #include <time.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -89,6 +90,59 @@ struct rtmi_scene {
 };
 
 extern "C" const char *rtmi_last_error(void) { return g_err.c_str(); }
+
+// Per-sample buffers outlive their handle, one per device: a destroyed handle parks its buffer here and the next
+// handle on that device takes it over when it is large enough.  Why: hipMalloc of tens of GB right after a hipFree of
+// the same size stalls for SECONDS now and then on this stack (profiles/r04_experiments/first_call_probe.log: 0.3 ms
+// nine times, then 4.6 s and 5.0 s for the same 25 GB; the r03 bench record shows one such stall as a 1.3 s first
+// call), and a host that renders one image per handle (rtmi_render_multi, Camera::render — the reference's usage
+// model is one render per process, tests/test.rs:802-838) would meet it again and again.  At most one buffer per device
+// is parked; rtmi_release_cached() returns the memory.
+namespace {
+struct ParkedSamples { void *ptr = nullptr; size_t bytes = 0; };
+std::mutex g_parked_mu;
+std::map<int, ParkedSamples> g_parked;
+// takes the parked buffer of `device` if it holds at least `need` bytes
+bool parked_take(int device, size_t need, void **ptr, size_t *bytes) {
+    std::lock_guard<std::mutex> lock(g_parked_mu);
+    auto it = g_parked.find(device);
+    if (it == g_parked.end() || !it->second.ptr || it->second.bytes < need) return false;
+    *ptr = it->second.ptr; *bytes = it->second.bytes;
+    g_parked.erase(it);
+    return true;
+}
+size_t parked_bytes(int device) {
+    std::lock_guard<std::mutex> lock(g_parked_mu);
+    auto it = g_parked.find(device);
+    return it == g_parked.end() ? 0 : it->second.bytes;
+}
+// frees what is parked on `device` (the current HIP device must be `device`)
+void parked_drop(int device) {
+    std::lock_guard<std::mutex> lock(g_parked_mu);
+    auto it = g_parked.find(device);
+    if (it == g_parked.end()) return;
+    if (it->second.ptr) (void)hipFree(it->second.ptr);
+    g_parked.erase(it);
+}
+// parks `ptr` (no kernel uses it any more) unless a larger one is parked already; the loser is freed
+void parked_give(int device, void *ptr, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_parked_mu);
+    ParkedSamples &slot = g_parked[device];
+    if (slot.ptr && slot.bytes >= bytes) { (void)hipFree(ptr); return; }
+    if (slot.ptr) (void)hipFree(slot.ptr);
+    slot.ptr = ptr; slot.bytes = bytes;
+}
+} // namespace
+
+extern "C" void rtmi_release_cached(void) {
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    std::lock_guard<std::mutex> lock(g_parked_mu);
+    for (auto &kv : g_parked)
+        if (kv.second.ptr && hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second.ptr);
+    g_parked.clear();
+    if (have_cur) (void)hipSetDevice(cur);
+}
 
 extern "C" int rtmi_device_count(void) {
     int n = 0;
@@ -278,7 +332,10 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         for (rtmi_item &it : items) {
             it.flags &= (RTMI_ITEMFLAG_FLIP | RTMI_ITEMFLAG_MEDIUM | (15u << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT));
             if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && it.kind == RTMI_ITEM_LIST && it.count == 1 &&
-                d->prim_meta[it.first].type == RTMI_PRIM_SPHERE) {
+                d->prim_meta[it.first].type == RTMI_PRIM_SPHERE &&
+                ((d->prim_meta[it.first].flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) == 0u) {
+                // (a sphere with a transform chain of its own — ConstantMedium(HittableList[Traslate(Sphere)]) — takes the
+                // general boundary query, which applies the chain; the fused query reads the raw centre)
                 it.flags |= RTMI_ITEMFLAG_DEV_MEDIUM_SPHERE;
                 memcpy(it.root_min, d->prim_a + (size_t)it.first * 4, 3 * sizeof(float));
                 it.root_max[0] = d->prim_a[(size_t)it.first * 4 + 3];
@@ -401,7 +458,10 @@ extern "C" void rtmi_scene_destroy(rtmi_scene *s) {
     (void)hipSetDevice(s->device);
     for (void *p : s->allocs) (void)hipFree(p);
     if (s->partial) (void)hipFree(s->partial);
-    if (s->samples) (void)hipFree(s->samples);
+    if (s->samples) { // parked for the next handle on this device (see g_parked); no kernel may still write it
+        if (s->busy_recorded) (void)hipEventSynchronize(s->busy);
+        parked_give(s->device, s->samples, s->samples_bytes);
+    }
     if (s->spill) (void)hipFree(s->spill);
     if (s->texels) (void)hipFree(s->texels);
     if (s->d_sig) (void)hipFree(s->d_sig);
@@ -454,13 +514,23 @@ static int plan_and_reserve(rtmi_scene *s, const rtmi_render_params *p, uint32_t
         if (!p->sample_buffer_bytes) { // default budget: never more than 3/4 of what is free on the device
             size_t free_b = 0, total_b = 0;
             HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-            const size_t avail = (free_b + s->samples_bytes) / 4 * 3;
+            const size_t avail = (free_b + s->samples_bytes + parked_bytes(s->device)) / 4 * 3;
             if (max_pass * per_sample > avail) max_pass = avail / per_sample ? avail / per_sample : 1;
         }
         if (max_pass * per_sample > s->samples_bytes) {
-            if (s->samples) { HIP_TRY(hipFree(s->samples)); s->samples = nullptr; s->samples_bytes = 0; }
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->samples), max_pass * per_sample));
-            s->samples_bytes = max_pass * per_sample;
+            const size_t need = max_pass * per_sample;
+            void *taken = nullptr;
+            size_t taken_bytes = 0;
+            if (parked_take(s->device, need, &taken, &taken_bytes)) { // a destroyed handle's buffer: no hipMalloc
+                if (s->samples) parked_give(s->device, s->samples, s->samples_bytes); // (smaller than the one taken)
+                s->samples = static_cast<Rad3 *>(taken);
+                s->samples_bytes = taken_bytes;
+            } else {
+                if (s->samples) { HIP_TRY(hipFree(s->samples)); s->samples = nullptr; s->samples_bytes = 0; }
+                parked_drop(s->device); // too small to serve this call: its memory may be what the allocation needs
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&s->samples), need));
+                s->samples_bytes = need;
+            }
         }
     }
     // unit = (tile, chunk of the sample range), the grain of the persistent wavefronts' queue.  Lanes
@@ -992,7 +1062,23 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 std::mutex g_rccl_mutex;
-std::map<std::vector<int>, std::vector<void *>> g_comms; // one communicator set per device list, for the process lifetime
+// Communicator sets are expensive to make (ncclCommInitAll) and RCCL allows ONE thread at a time to enqueue on a
+// communicator: a set belongs to exactly one rtmi_multi handle while that handle lives (checked out at create,
+// handed back at destroy) and is kept for the next handle on the same device list afterwards, so that one-shot
+// calls (rtmi_render_multi) do not pay the initialisation per image and two live handles on one device list never
+// share communicators.  Sets live for the process lifetime.
+struct CommSet {
+    std::vector<void *> comms;
+    bool busy = false;
+};
+std::map<std::vector<int>, std::vector<CommSet *>> g_comm_pool;
+// RTMI_FORCE_RCCL=1 (environment, read at every rtmi_multi_create): also a ONE-entry device list gets a communicator,
+// so that the whole collective path — dlopen, ncclCommInitAll, grouped ncclGather on the render stream — runs on a
+// single GPU (tests, and bench.py's abi_multi leg at N = 1).  Without it a one-device handle needs no exchange.
+bool force_rccl() {
+    const char *e = getenv("RTMI_FORCE_RCCL");
+    return e && *e && *e != '0';
+}
 } // namespace
 #define RCCL_TRY(expr)                                                                                        \
     do {                                                                                                      \
@@ -1011,7 +1097,7 @@ struct rtmi_multi {
     rtmi_texel *gathered = nullptr;      // on devices[0]: n x stride texels, rank-major
     rtmi_texel *h_gathered = nullptr;    // its pinned host mirror
     size_t h_count = 0;
-    std::vector<void *> comms;           // RCCL communicators (distinct devices, n > 1), made at create
+    CommSet *commset = nullptr;          // RCCL communicators (distinct devices; n > 1 or RTMI_FORCE_RCCL), checked out at create
     std::mutex mu;                       // render calls on one handle serialise (rtmi.h, thread model)
 };
 
@@ -1022,7 +1108,11 @@ extern "C" void rtmi_multi_destroy(rtmi_multi *m) {
     if (m->gathered) { (void)hipSetDevice(m->devices[0]); (void)hipFree(m->gathered); }
     if (m->h_gathered) (void)hipHostFree(m->h_gathered);
     for (rtmi_scene *s : m->scenes) rtmi_scene_destroy(s);
-    delete m; // the communicators stay cached per device list for the process lifetime (g_comms)
+    if (m->commset) { // back to the pool: the next handle on this device list takes it over
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        m->commset->busy = false;
+    }
+    delete m;
 }
 
 extern "C" int rtmi_multi_create(const rtmi_scene_desc *desc, const int *devices, uint32_t n, rtmi_multi **out) {
@@ -1062,20 +1152,30 @@ extern "C" int rtmi_multi_create(const rtmi_scene_desc *desc, const int *devices
     }
     for (uint32_t i = 0; i < n; i++)
         if (rcs[i] != RTMI_OK) return fail(rcs[i], "device " + std::to_string(devices[i]) + ": " + errs[i]);
-    if (m->distinct && n > 1) { // communicators at create, not in the first render
+    if (m->distinct && (n > 1 || force_rccl())) { // communicators at create, not in the first render
         std::lock_guard<std::mutex> lock(g_rccl_mutex);
         if (!g_rccl.load()) return fail(RTMI_ERR_DEVICE, g_rccl.err);
-        auto it = g_comms.find(m->devices);
-        if (it == g_comms.end()) {
-            std::vector<void *> c(n, nullptr);
-            RCCL_TRY(g_rccl.CommInitAll(c.data(), (int)n, devices));
-            it = g_comms.emplace(m->devices, c).first;
+        std::vector<CommSet *> &pool = g_comm_pool[m->devices];
+        for (CommSet *c : pool)
+            if (!c->busy) { m->commset = c; break; }
+        if (!m->commset) {
+            CommSet *c = new CommSet();
+            c->comms.assign(n, nullptr);
+            int r = g_rccl.CommInitAll(c->comms.data(), (int)n, devices);
+            if (r != 0) { delete c; return fail(RTMI_ERR_DEVICE, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
+            pool.push_back(c);
+            m->commset = c;
         }
-        m->comms = it->second;
+        m->commset->busy = true;
     }
     guard.m = nullptr;
     *out = m;
     return RTMI_OK;
+}
+
+extern "C" int rtmi_multi_collective(const rtmi_multi *m) {
+    if (!m) return -1;
+    return m->commset ? RTMI_COLLECTIVE_RCCL : (m->devices.size() > 1 ? RTMI_COLLECTIVE_PEER_COPY : RTMI_COLLECTIVE_NONE);
 }
 
 // whole-image parameters -> per-device parameters; validates what the multi-device entry points accept
@@ -1095,6 +1195,7 @@ static int multi_reserve_texels(rtmi_multi *m, const rtmi_render_params *p0) {
     const uint32_t n = (uint32_t)m->devices.size();
     const size_t stride = (size_t)local_tiles_of(p0, 0) * 64;
     if (stride > m->stride) {
+        m->stride = 0; // nothing is valid until every allocation below has succeeded
         for (uint32_t i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(m->devices[i]));
             if (m->texels[i]) { HIP_TRY(hipFree(m->texels[i])); m->texels[i] = nullptr; }
@@ -1104,7 +1205,6 @@ static int multi_reserve_texels(rtmi_multi *m, const rtmi_render_params *p0) {
         }
         HIP_TRY(hipSetDevice(m->devices[0]));
         if (m->gathered) { HIP_TRY(hipFree(m->gathered)); m->gathered = nullptr; }
-        m->stride = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->gathered), (size_t)n * stride * sizeof(rtmi_texel)));
         m->stride = stride;
     }
@@ -1146,12 +1246,12 @@ extern "C" int rtmi_multi_render(rtmi_multi *m, const rtmi_camera *cam, const rt
         done[i] = s->ev[2];
     }
     // the ONE exchange of the path: tile-packed framebuffers -> devices[0]
-    if (!m->comms.empty()) {
+    if (m->commset) {
         RCCL_TRY(g_rccl.GroupStart());
         for (uint32_t i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(m->devices[i]));
             // (recvbuff is read on the root only; the others pass a valid device pointer rather than NULL for argument checkers)
-            RCCL_TRY(g_rccl.Gather(m->texels[i], i == 0 ? m->gathered : m->texels[i], stride * sizeof(rtmi_texel), /*ncclInt8*/ 0, 0, m->comms[i], m->scenes[i]->stream));
+            RCCL_TRY(g_rccl.Gather(m->texels[i], i == 0 ? m->gathered : m->texels[i], stride * sizeof(rtmi_texel), /*ncclInt8*/ 0, 0, m->commset->comms[i], m->scenes[i]->stream));
         }
         RCCL_TRY(g_rccl.GroupEnd());
     } else {

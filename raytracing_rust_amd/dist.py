@@ -20,8 +20,21 @@ def env_rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_process_group(backend=None):
-    """torch.distributed from the torchrun environment (MASTER_ADDR must be 127.0.0.1 on one node)."""
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def init_process_group(backend=None, collective_at_1=False):
+    """torch.distributed from the torchrun environment (MASTER_ADDR must be 127.0.0.1 on one node).
+    collective_at_1: also a single rank makes its (one-rank) process group, so that gather_framebuffer() really
+    crosses the backend — under "nccl" that is RCCL's communicator set-up and one ncclGather-shaped exchange per
+    image on the one GPU of a one-GPU box, the same code the N > 1 ranks run.  Costs microseconds per image."""
     import torch
     import torch.distributed as dist
 
@@ -30,9 +43,9 @@ def init_process_group(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or collective_at_1) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", "29511" if world > 1 else str(_free_port()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -56,8 +69,8 @@ def gather_framebuffer(local, rank, world, group=None):
     import torch
     import torch.distributed as dist
 
-    if world == 1:
-        return local.unsqueeze(0)
+    if world == 1 and not dist.is_initialized():
+        return local.unsqueeze(0)  # no process group: nothing to cross (init_process_group(collective_at_1=True) makes one)
     if rank == 0:
         out = [torch.empty_like(local) for _ in range(world)]
         dist.gather(local, gather_list=out, dst=0, group=group)

@@ -169,6 +169,11 @@ class Scene:
         self.multi_devices = list(devices)
         return self
 
+    def multi_collective(self):
+        """Which exchange render_resident() performs: "none" (one device), "peer_copy" (a device listed twice) or
+        "rccl" (one grouped ncclGather; distinct devices, or one device with RTMI_FORCE_RCCL=1 at upload_multi)."""
+        return {0: "none", 1: "peer_copy", 2: "rccl"}.get(self.host.lib.rth_multi_collective(self.h), "no handle")
+
     def free_multi(self):
         self.host._check(self.host.lib.rth_multi_free(self.h))
         self.multi_devices = None
@@ -412,6 +417,11 @@ class Host:
         pm = np.zeros(768, np.int32)
         self._check(self.lib.rth_perlin_tables(tex.h, rv.ctypes.data, pm.ctypes.data))
         return rv.reshape(256, 3), pm.reshape(3, 256)
+
+
+def release_cached():
+    """Returns the per-sample buffers that destroyed handles left parked for their successors (rtmi_release_cached)."""
+    abi.load_rtmi().rtmi_release_cached()
 
 
 def ppm_p3(rgb8):

@@ -428,6 +428,8 @@ class DeviceScene {
     void prepare(uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt = {});
     Image render(const Camera &cam, uint32_t nx, uint32_t ny, uint32_t ns, const RenderOptions &opt = {});
     const std::vector<int> &devices() const { return devices_; }
+    // RTMI_COLLECTIVE_*: what brings the tiles of a render together (one ncclGather for distinct devices)
+    int collective() const { return rtmi_multi_collective(handle_); }
 
   private:
     std::vector<int> devices_;

@@ -297,6 +297,11 @@ RTH_API int rth_multi_free(void *lowered) {
         return RTH_OK;
     });
 }
+// which exchange the resident handle's renders perform (RTMI_COLLECTIVE_*), -1 without a handle
+RTH_API int rth_multi_collective(void *lowered) {
+    Obj *o = LOW(lowered);
+    return o && o->multi ? rtmi_multi_collective(o->multi) : -1;
+}
 RTH_API int rth_multi_prepare(void *lowered, const rtmi_render_params *p) {
     return guard([&] {
         Obj *o = LOW(lowered);

@@ -138,6 +138,14 @@ def random_scene(api, seed, only=None, instanced=False):
             b = api.Sphere(rng.uniform(-2, 2, 3), float(rng.uniform(0.8, 2.0)), api.Dielectric(1.5)) if rng.random() < 0.5 \
                 else api.Cube(rng.uniform(-2.5, 0, 3), rng.uniform(0.5, 2.5, 3), api.Dielectric(1.5))
             b = _wrap(api, rng, b, allow_flip=False)
+            if instanced and rng2.random() < 0.3:
+                # the boundary as a ONE-member list whose member carries its own transform chain:
+                # ConstantMedium(HittableList[Traslate(Rotate(Sphere))]) — the device must not take its fused
+                # sphere-boundary query here (r03 advisor finding: that query read the untransformed centre)
+                lst = api.HittableList()
+                q = api.Sphere(rng2.uniform(-2, 2, 3), float(rng2.uniform(0.8, 2.0)), api.Dielectric(1.5))
+                lst.push(_wrap(api, rng2, api.Traslate(q, rng2.uniform(-1.0, 1.0, 3)), allow_flip=False))
+                b = lst
             med = api.ConstantMedium(b, float(rng.choice([0.0, 0.01, 0.2, 1.0, 5.0])), _texture(api, rng))
             if instanced and rng2.random() < 0.5:
                 med = _wrap(api, rng2, med)  # Traslate / Rotate / FlipNormals AROUND the medium (traslate.rs:6-9 is generic)

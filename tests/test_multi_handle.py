@@ -6,6 +6,7 @@ The loop the handle shards is create_image's (tests/test.rs:62-79); the referenc
 single thread holding Rc's (src/bvh.rs:11-12).  CPU tests cover argument validation, symbol export and the
 thread-locality of rtmi_last_error; the GPU tests compare with rtmi_render bit-for-bit."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -14,6 +15,8 @@ import pytest
 import scenes_extra
 from raytracing_rust_amd import abi
 from raytracing_rust_amd.host import HostError, default_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # ------------------------------------------------------------------------------------------------ CPU
@@ -217,3 +220,108 @@ def test_c5_x5000_as_eight_ranks_through_the_multi_handle(host):
     print("1 rank: %.0f ms, mean radiance %.4f" % (one["stats"]["kernel_ms"], float(one["linear"].mean())))
     assert float(one["linear"].mean()) > 0.01
     assert np.array_equal(res["linear"], one["linear"]) and np.array_equal(res["rgb8"], one["rgb8"])
+
+
+# ------------------------------------------------------------------------------------------------ RCCL on one GPU
+@pytest.mark.gpu
+def test_one_rank_rccl_gather_through_the_multi_handle(host, monkeypatch):
+    """Every line of the collective path that ONE GPU can execute: with RTMI_FORCE_RCCL=1 a one-entry device list gets a
+    one-rank communicator — dlopen(librccl) -> six dlsym -> ncclCommInitAll(1) at create, ncclGroupStart / ncclGather /
+    ncclGroupEnd on the scene's stream in every render, D2H, un-tiling — and rtmi_multi_collective() says so.  Image ==
+    rtmi_render's bit for bit; without the knob the same list reports no exchange; a device listed twice reports peer
+    copies.  The loop whose tiles the gather brings together: tests/test.rs:62-70.
+    Also the communicator pool: two LIVE handles on the same list hold different sets (they may render from two
+    threads), a destroyed handle's set is taken over by the next create."""
+    nx, ny, ns = 200, 120, 24
+    cam, world = scenes_extra.build(host, "lit_final_scene", nx, ny, seed=1)
+    sc = host.lower(world)
+    sc.upload(0)
+    want = sc.render(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+    assert want["linear"].mean() > 0.01
+    monkeypatch.delenv("RTMI_FORCE_RCCL", raising=False)
+    sc.upload_multi([0])
+    assert sc.multi_collective() == "none"
+    sc.upload_multi([0, 0])
+    assert sc.multi_collective() == "peer_copy"
+    sc.free_multi()
+    monkeypatch.setenv("RTMI_FORCE_RCCL", "1")
+    sc.upload_multi([0])
+    try:
+        assert sc.multi_collective() == "rccl"
+        for rep in range(3):
+            got = sc.render_resident(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+            assert np.array_equal(got["linear"], want["linear"]) and np.array_equal(got["rgb8"], want["rgb8"]), rep
+        # a second live handle on the same list: its own communicator; both render at the same time
+        sc2 = host.lower(world)
+        sc2.upload_multi([0])
+        try:
+            assert sc2.multi_collective() == "rccl"
+            errs = []
+
+            def work(s):
+                try:
+                    for _ in range(3):
+                        r = s.render_resident(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+                        assert np.array_equal(r["rgb8"], want["rgb8"]) and np.array_equal(r["linear"], want["linear"])
+                except BaseException as e:  # noqa: BLE001
+                    errs.append(repr(e))
+
+            ts = [threading.Thread(target=work, args=(s,)) for s in (sc, sc2)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+            assert not errs, errs
+        finally:
+            sc2.free_multi()
+        # the one-shot form takes a pooled set over (no ncclCommInitAll per image) and gives the same image
+        shot = sc.render_multi(cam, nx, ny, ns, [0], seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+        assert np.array_equal(shot["linear"], want["linear"])
+    finally:
+        sc.free_multi()
+
+
+@pytest.mark.gpu
+def test_one_rank_torch_distributed_nccl_gather_in_a_fresh_process(tmp_path):
+    """dist.py's host at world 1 under backend "nccl": init_process_group(collective_at_1=True) + gather_framebuffer
+    really call torch.distributed (RCCL communicator of one rank, one gather per image) — the code the N > 1 ranks of
+    bench.py run — and the image equals the blocking single-device render.  In a fresh child: a process group is made
+    once per process, and this test process may already hold one."""
+    import subprocess
+    import sys
+
+    code = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import scenes_extra
+from raytracing_rust_amd import Host, abi, dist as rdist
+host = Host()
+nx, ny, ns = 160, 96, 16
+cam, world = scenes_extra.build(host, "lit_final_scene", nx, ny, seed=1)
+sc = host.lower(world); sc.upload(0)
+want = sc.render(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+rank, world_n, local_rank = rdist.init_process_group("nccl", collective_at_1=True)
+assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+dev = torch.device("cuda", 0)
+p = rdist.rank_params(nx, ny, ns, rank, world_n, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+local = rdist.new_local_framebuffer(p, dev)
+stream = torch.cuda.current_stream(dev)
+for rep in range(3):
+    sc.render_device(cam, p, local.data_ptr(), stream.cuda_stream)
+    g = rdist.gather_framebuffer(local, rank, world_n)
+    assert g.data_ptr() != local.data_ptr()  # the gather's own output buffer, not a view of the input
+torch.cuda.synchronize(); dist.barrier(); sc.check_status()
+lin, rgb = rdist.untile(p, g.cpu().numpy())
+dist.destroy_process_group()
+print(json.dumps({"equal": bool(np.array_equal(lin, want["linear"]) and np.array_equal(rgb, want["rgb8"])),
+                  "mean": float(lin.mean())}))
+''' % (ROOT, ROOT)
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None); env.pop("MASTER_PORT", None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cp = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert cp.returncode == 0, cp.stderr.decode(errors="replace")[-2000:]
+    import json
+
+    res = json.loads(cp.stdout.decode().strip().splitlines()[-1])
+    assert res["equal"] and res["mean"] > 0.01, res

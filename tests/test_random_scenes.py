@@ -234,6 +234,61 @@ def test_list_as_bvh_leaf_matches_the_fp32_oracle(host, orc32):
     orc32.free_all()
 
 
+def _medium_in_instanced_list_world(api):
+    """ConstantMedium over a ONE-member HittableList whose member is an instanced sphere (medium.rs:11-15 takes any
+    Hittable as boundary; traslate.rs:6-9 / rotate.rs:21-28 wrap any Hittable): the smoke must sit where the wrappers
+    put the sphere, (1.5, 1.0, 0.5) here, not at the raw centre (0, 0, 0)."""
+    w = api.HittableList()
+    w.push(api.Rect(api.PLANE_ZX, -6.0, -6.0, 6.0, 6.0, -1.0, api.Lambertian(api.SolidTexture(0.6, 0.6, 0.6))))
+    w.push(api.Sphere((0.0, 9.0, 0.0), 3.0, api.DiffuseLight(api.SolidTexture(5.0, 5.0, 5.0))))
+    lst = api.HittableList()
+    ball = api.Sphere((0.0, 0.0, 0.0), 1.0, api.Dielectric(1.5))
+    lst.push(api.Traslate(api.Rotate(api.AXIS_Z, ball, 30.0), (1.5, 1.0, 0.5)))
+    w.push(api.ConstantMedium(lst, 2.0, api.SolidTexture(0.9, 0.2, 0.2)))
+    # a plain one: the fused boundary query must still serve it
+    w.push(api.ConstantMedium(api.Sphere((-1.5, 0.2, 0.0), 0.9, api.Dielectric(1.5)), 1.0, api.SolidTexture(0.2, 0.9, 0.2)))
+    return w
+
+
+@pytest.mark.gpu
+def test_medium_over_a_list_with_an_instanced_sphere_matches_the_fp32_oracle(host, orc32):
+    """r03 advisor finding: rtmi_scene_create chose the fused sphere-boundary query for ANY medium over a one-sphere list
+    and ignored the sphere's own transform chain; the cooperative kernels then disagreed with the per-lane ones."""
+    nx, ny, ns = 96, 64, 24
+    worlds, cams = [], []
+    for api in (host, orc32):
+        worlds.append(_medium_in_instanced_list_world(api))
+        cams.append(api.Camera((0.5, 1.5, 7.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 40.0, nx / ny, 0.05, 7.0, 0.0, 1.0))
+    sc = host.lower(worlds[0])
+    a = sc.arrays()
+    med = [it for it in a["items"] if it.flags & abi.ITEMFLAG_MEDIUM]
+    assert len(med) == 2 and med[0].count == 1
+    assert (a["prim_meta"][med[0].first].flags >> abi.RTMI_PRIMFLAG_XF_COUNT_SHIFT) & 15 == 2  # the chain is the primitive's
+    ref = orc32.render(cams[1], worlds[1], nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM)
+    lin = ref["linear"]
+    # the red smoke is seen right of the centre (where the wrappers put it), the green one left
+    assert float((lin[..., 0] - lin[..., 1])[:, nx // 2:].max()) > 0.05 and float((lin[..., 1] - lin[..., 0])[:, :nx // 2].max()) > 0.05
+    for flags in (0, abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_FAST_CULL | abi.RTMI_FLAG_BLOCK_COOP,
+                  abi.RTMI_FLAG_SYNC | abi.RTMI_FLAG_FAST_CULL, abi.RTMI_FLAG_ASYNC | abi.RTMI_FLAG_FAST_CULL):
+        got = sc.render(cams[0], nx, ny, ns, seed=42, flags=flags, sig=True)
+        assert np.array_equal(got["sig"], ref["sig"]), flags
+        assert np.array_equal(got["linear"], ref["linear"]), flags
+        assert np.array_equal(got["rgb8"].astype(np.int32), ref["rgb"]), flags
+    orc32.free_all()
+
+
+def test_medium_over_a_list_with_an_instanced_sphere_mirror_equals_f64_oracle(host, orc64):
+    nx, ny = 24, 16
+    cams = [api.Camera((0.5, 1.5, 7.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 40.0, nx / ny, 0.05, 7.0, 0.0, 1.0) for api in (host, orc64)]
+    wh, wo = _medium_in_instanced_list_world(host), _medium_in_instanced_list_world(orc64)
+    for row in (5, 8, 11):
+        ref = orc64.render(cams[1], wo, nx, ny, 1, seed=42, rows=(row, row + 1))
+        for i in range(nx):
+            c = host.color_sample(cams[0], wh, nx, ny, i, ny - 1 - row, 0, seed=42)
+            assert np.array_equal(c, ref["mean"][row, i]), (row, i)
+    orc64.free_all()
+
+
 @pytest.mark.gpu
 def test_compositions_scene_matches_the_fp32_oracle(host, orc32):
     """The scene of tests/golden/flat_compositions.bin.gz (tools/dump_flat_scene.py: list leaves with ties, instanced
