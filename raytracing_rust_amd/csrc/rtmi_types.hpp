@@ -2,6 +2,7 @@
 // Part of the single translation unit rtmi_device.hip (device code is header-only so that every
 // kernel instantiation inlines the whole path); arithmetic contract as stated there.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -41,6 +42,11 @@ struct DevItem {
     rtmi_item it;     // 64 B
     rtmi_xform x0, x1; // xforms[it.xform_first], [.. + 1] (zeros when the chain is shorter)
 }; // 96 B
+// shade_hit (rtmi_shade.hpp) fetches the four shading words of the item record and its two embedded transforms by
+// byte offset, and the kernels load {x0, x1} as one pair from &items[i].x0: pin the layout those reads assume
+static_assert(sizeof(rtmi_item) == 64 && sizeof(rtmi_xform) == 16 && sizeof(DevItem) == 96, "DevItem layout");
+static_assert(offsetof(rtmi_item, flags) == 12 && offsetof(rtmi_item, medium_material) == 24, "item shading words at bytes 12..27");
+static_assert(offsetof(DevItem, x0) == 64 && offsetof(DevItem, x1) == 80, "embedded transforms at bytes 64 and 80");
 
 struct DevScene {
     const DevItem *items;

@@ -1,0 +1,79 @@
+"""The north star's "stated fp32 radiance tolerance", stated against the REFERENCE'S OWN ARITHMETIC at BASELINE size.
+
+The device computes in fp32 under the contract of DESIGN.md §4 and is bit-identical to the fp32 oracle
+(test_gpu_oracle_million.py).  What the reference computes is f64 (`Vector3<f64>`, src/color.rs:6-23): its literal
+restatement is the f64 oracle with flags 0 (recursive color, divisions where the reference divides).  Both sides take
+the same Philox streams (24-bit uniforms are exact in either precision), so a camera path differs only where fp32
+rounding moves a decision — a hit/miss at a grazing edge, a rejection-sampler trial at the unit sphere's surface, a
+dielectric's reflect/refract draw — after which that ONE path of the pixel's ns goes elsewhere and the pixel mean moves
+by (radiance of the path) / ns.  This test measures and bounds that on
+  * BASELINE C3 cornell_box 800x800x1000 spp (the one lit BASELINE config), 64 evenly spaced rows = 51.2 M paths,
+  * lit_final_scene 480x270x1000 spp (C5's object graph with the light the right way round), every 2nd row = 64.8 M paths,
+in forked oracle workers (oracle/parallel.py).  The measured figures are printed, asserted with some slack, and quoted
+in DESIGN.md §6.  Reference loop: tests/test.rs:62-78."""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle.parallel import render_parallel
+from raytracing_rust_amd import abi
+
+import scenes_extra
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def compare(host, name, nx, ny, ns, rows):
+    cam, world = scenes_extra.build(host, name, nx, ny, seed=1)
+    sc = host.lower(world).upload(0)
+    got = sc.render(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL)
+    t0 = time.perf_counter()
+    ref = render_parallel("scenes_extra", name, nx, ny, ns, 42, 0, precision="f64", rows=rows, timeout=1500)
+    dt = time.perf_counter() - t0
+    d = np.abs(got["linear"][rows].astype(np.float64) - ref["mean"][rows])  # linear radiance, per channel
+    lev = np.abs(got["rgb8"][rows].astype(np.int32) - ref["rgb"][rows])     # PPM values (0..255)
+    mean_ref = float(ref["mean"][rows].mean())
+    res = {
+        "scene": "%s %dx%dx%d" % (name, nx, ny, ns), "rows": len(rows), "paths": len(rows) * nx * ns, "oracle_s": round(dt, 1),
+        "mean_radiance_f64": mean_ref,
+        "image_mean_rel_err": abs(float(got["linear"][rows].astype(np.float64).mean()) - mean_ref) / mean_ref,
+        "share_within_1e-4": float((d <= 1e-4).mean()), "share_within_1e-3": float((d <= 1e-3).mean()),
+        "share_within_1e-2": float((d <= 1e-2).mean()), "share_identical_to_f32_rounding": float((d <= 1e-6 * np.maximum(1.0, ref["mean"][rows])).mean()),
+        "max_abs": float(d.max()), "mean_abs": float(d.mean()), "p99_abs": float(np.quantile(d, 0.99)),
+        "ppm_values_differing": float((lev > 0).mean()), "ppm_values_differing_by_more_than_1": float((lev > 1).mean()),
+        "ppm_max_level_diff": int(lev.max()),
+    }
+    print(json.dumps(res))
+    out = os.path.join(ROOT, "gpurun_out", "f64_tolerance_%s.json" % name)
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump(res, open(out, "w"), indent=1)
+    except OSError:
+        pass
+    return res
+
+
+def test_c3_cornell_box_fullsize_against_the_f64_literal(host):
+    nx, ny, ns = 800, 800, 1000
+    rows = [int((k + 0.5) * ny / 64) for k in range(64)]
+    r = compare(host, "cornell_box", nx, ny, ns, rows)
+    assert r["mean_radiance_f64"] > 0.05
+    # measured (MI355X, r04): see DESIGN.md §6 "Stated tolerance against the reference's f64 arithmetic"
+    assert r["image_mean_rel_err"] <= 2e-4
+    assert r["share_within_1e-3"] >= 0.80 and r["share_within_1e-2"] >= 0.995
+    assert r["mean_abs"] <= 1e-3 and r["ppm_values_differing_by_more_than_1"] <= 0.002 and r["ppm_max_level_diff"] <= 12
+
+
+def test_lit_final_scene_against_the_f64_literal(host):
+    nx, ny, ns = 480, 270, 1000
+    rows = list(range(0, ny, 2))
+    r = compare(host, "lit_final_scene", nx, ny, ns, rows)
+    assert r["mean_radiance_f64"] > 0.01
+    assert r["image_mean_rel_err"] <= 5e-4
+    assert r["share_within_1e-3"] >= 0.80 and r["share_within_1e-2"] >= 0.995
+    assert r["mean_abs"] <= 1e-3 and r["ppm_values_differing_by_more_than_1"] <= 0.002 and r["ppm_max_level_diff"] <= 12

@@ -46,3 +46,20 @@ def test_two_million_paths_match_the_fp32_oracle_bit_for_bit(host, name, budget)
     assert int(np.count_nonzero(ref["sig"])) > 0.3 * NX * NY  # the paths are pinned even where the image is black
     if name in ("cornell_box", "lit_final_scene"):
         assert float(ref["linear"].mean()) > 0.01
+
+
+def test_baseline_c1_two_spheres_at_its_literal_size(host):
+    """BASELINE.json configs[0] as written — two_spheres 400x225x100 spp, depth 50 (9.0 M camera paths; the reference's
+    own CPU-runnable case, tests/test.rs:165-182 with the camera of :582-593): device == fp32 oracle bit for bit
+    (radiance — identically zero, F4/F5 of SURVEY.md —, quantised image, and the path signatures that pin the
+    geometry of every bounce)."""
+    nx, ny, ns = 400, 225, 100
+    cam, world = scenes_extra.build(host, "two_spheres", nx, ny, seed=1)
+    sc = host.lower(world).upload(0)
+    got = sc.render(cam, nx, ny, ns, seed=42, flags=abi.RTMI_FLAG_FAST_CULL, sig=True)
+    t0 = time.perf_counter()
+    ref = render_parallel("scenes_extra", "two_spheres", nx, ny, ns, 42, ARITH_DEVICE | THROUGHPUT_FORM, band=3)
+    print("two_spheres 400x225x100: oracle %.1f s, device %.1f ms" % (time.perf_counter() - t0, got["stats"]["kernel_ms"]))
+    assert np.array_equal(got["sig"], ref["sig"]) and int(np.count_nonzero(ref["sig"])) > 0.3 * nx * ny
+    assert np.array_equal(got["linear"], ref["linear"]) and np.array_equal(got["rgb8"].astype(np.int32), ref["rgb"])
+    assert int(got["rgb8"].max()) == 0  # the reference's image of this scene is black (no emitter, black background)
