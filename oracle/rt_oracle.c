@@ -41,6 +41,7 @@
 #ifdef ORC_F32
 typedef float REAL;
 #define R_SQRT sqrtf
+#define R_FMA fmaf
 #define R_FMAX fmaxf
 #define R_FMIN fminf
 #define R_FLOOR floorf
@@ -50,6 +51,7 @@ typedef float REAL;
 #else
 typedef double REAL;
 #define R_SQRT sqrt
+#define R_FMA fma
 #define R_FMAX fmax
 #define R_FMIN fmin
 #define R_FLOOR floor
@@ -557,6 +559,17 @@ static int sphere_hit_at(V3 center, REAL radius, const Material *mat, const Ray 
     REAL b = v_dot(oc, r->d);
     REAL c = v_dot(oc, oc) - radius * radius;
     REAL disc = b * b - a * c;
+    if (DEVICE_ARITH) {
+        /* contract substitution 5: the same discriminant as a (r^2 - |oc - (b/a) d|^2) — the squared
+         * distance of the centre from the ray instead of a difference of two numbers of size |oc|^2 a, which in fp32
+         * puts the hit point of a small far sphere up to 5e-3 off its surface (the scattered ray then meets the same
+         * sphere again beyond t_min: final_scene's small spheres 10 % too dark against the f64 literal).  Explicit
+         * fma (one rounding each) exactly as csrc/rtmi_geom.hpp sphere_disc(). */
+        REAL q = b * r->inv_a;
+        REAL lx = R_FMA(-q, r->d.x, oc.x), ly = R_FMA(-q, r->d.y, oc.y), lz = R_FMA(-q, r->d.z, oc.z);
+        REAL l2 = R_FMA(lz, lz, R_FMA(ly, ly, lx * lx));
+        disc = a * (radius * radius - l2);
+    }
     if (disc > 0) {
         REAL sq = R_SQRT(disc);
         REAL t = DEVICE_ARITH ? (-b - sq) * r->inv_a : (-b - sq) / a;

@@ -16,7 +16,8 @@ _ROOT = os.path.dirname(_PKG)
 LIB_DIR = os.environ.get("RTMI_LIB_DIR") or os.path.join(_PKG, "lib")
 INCLUDE = os.path.join(_ROOT, "include")
 
-RTMI_SRC = [os.path.join(_PKG, "csrc", "rtmi_device.hip"), os.path.join(_PKG, "csrc", "rtmi_lean.hip")]
+RTMI_SRC = [os.path.join(_PKG, "csrc", "rtmi_device.hip"), os.path.join(_PKG, "csrc", "rtmi_lean.hip"),
+            os.path.join(_PKG, "csrc", "rtmi_alt.hip")]
 HOST_SRC = [os.path.join(_PKG, "host", "rt_host.cpp"), os.path.join(_PKG, "host", "rt_host_c.cpp")]
 RTMI_DEPS = RTMI_SRC + sorted(glob.glob(os.path.join(_PKG, "csrc", "*.hpp"))) + [
     os.path.join(INCLUDE, "rtmi.h"), os.path.join(INCLUDE, "rtmi_math.h")]
@@ -60,11 +61,16 @@ def build_rtmi(force=False, verbose=False):
               "-I" + INCLUDE]
     if verbose:
         common.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    objs = []
-    for src, flags in ((RTMI_SRC[0], sched), (RTMI_SRC[1], [])):
+    # three translation units, compiled side by side: the headline kernels (rtmi_device.hip), the lean instantiations
+    # with the default scheduler (rtmi_lean.hip), and the two alternative kernels kept for the parity tests (rtmi_alt.hip)
+    objs, procs = [], []
+    for src, flags in ((RTMI_SRC[0], sched), (RTMI_SRC[1], []), (RTMI_SRC[2], sched)):
         obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + ".o")
-        subprocess.run(common + flags + extra + ["-c", src, "-o", obj], check=True)
+        procs.append((src, subprocess.Popen(common + flags + extra + ["-c", src, "-o", obj])))
         objs.append(obj)
+    failed = [src for src, p in procs if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, "hipcc -c " + " ".join(failed))
     subprocess.run([_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIBRTMI] + objs, check=True)
     return LIBRTMI
 

@@ -26,10 +26,7 @@
 //     Push positions come from one LDS atomicAdd per wavefront and round on one of two alternating counters.
 // Alternative (gated 4-wide) trees only: the host selects this kernel when every BVH item has one.
 // ----------------------------------------------------------------------------------
-#define RTMI_BLK_WAVES 4
-#define RTMI_BLK_THREADS (64 * RTMI_BLK_WAVES)
-// LDS of a workgroup in uint32 words: pool [cap][2] | ctx [4][T][4] | best [T][2] | dummy [T][2] | sync [16]
-#define RTMI_BLK_LDS_WORDS(cap) (2u * (cap) + RTMI_BLK_THREADS * 20u + 16u)
+// (RTMI_BLK_WAVES / RTMI_BLK_THREADS / RTMI_BLK_LDS_WORDS: rtmi_kernels.hpp, next to the kernel declarations the launcher uses)
 
 struct BlockWork {
     uint2 *pool;              // [cap] shared LIFO

@@ -55,13 +55,9 @@ struct CoopWork {
 // W4: `root` is a node of the 4-wide alternative tree (sc.nodes4, always gated); a visit tests four child boxes,
 // keeps the nearest surviving child and pushes up to three.  Half the chain length of a binary tree: the
 // traversals are bound by their longest chain, not by their work.
-#ifdef RTMI_COOP_OUTLINE /* experiment (r03): the traversal as a real function call instead of four inlined copies */
-#define RTMI_COOP_INLINE __attribute__((noinline))
-#else
 #define RTMI_COOP_INLINE __forceinline__
-#endif
 template <bool PROF, bool EXT, bool W4, bool INST>
-__device__ RTMI_COOP_INLINE void coop_bvh_query(const DevScene &sc, int root, bool gated, float scale, bool active, const RayF &R,
+__device__ __forceinline__ void coop_bvh_query(const DevScene &sc, int root, bool gated, float scale, bool active, const RayF &R,
                                                float time, float q_min, float q_max, const CoopWork &cw,
                                                bool &have, float &t_out, int &pf_out, bool &overflow,
                                                unsigned long long *prof, int slot) {

@@ -9,7 +9,7 @@
 // SGPRs) instead of 64 identical vector loads — fewer VALU address computations, fewer VGPRs, the vector memory
 // pipe left to the divergent gathers.  Legal because the scene arrays are never written while a render kernel
 // runs.  Measured: final_scene +2.1 %, cornell_box +6 %.
-#if !defined(RTMI_NO_SLOAD) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) /* (the host pass of hipcc parses this header too) */
 #define RTMI_UNIFORM_LOAD(T, ptr) (*reinterpret_cast<const T __attribute__((address_space(4))) *>(reinterpret_cast<uintptr_t>(ptr)))
 #else
 #define RTMI_UNIFORM_LOAD(T, ptr) (*(ptr))
@@ -110,7 +110,6 @@ __device__ __forceinline__ void ray_derive(RayF &r) {
 // AABB::hit — src/aabb.rs:31-44.  The sequential early-out is an OR of the three tests.
 __device__ __forceinline__ bool aabb_hit(float mnx, float mny, float mnz, float mxx, float mxy, float mxz,
                                          const RayF &r, float t_min, float t_max) {
-#ifndef RTMI_BRANCHY_TESTS
     // aabb.rs:41-43 returns false as soon as t_max <= t_min after an axis.  t_min never decreases and t_max never
     // increases from axis to axis (fmaxf / fminf, which also ignore a NaN slab distance exactly like f64::max / min),
     // so "after some axis" <=> "after the last axis": one comparison instead of three and their two mask ORs.
@@ -127,34 +126,29 @@ __device__ __forceinline__ bool aabb_hit(float mnx, float mny, float mnz, float 
     t_min = fmaxf(t_min, neg ? t1 : t0);
     t_max = fminf(t_max, neg ? t0 : t1);
     return !(t_max <= t_min);
-#else
-    float t0 = (mnx - r.o.x) * r.inv_d.x, t1 = (mxx - r.o.x) * r.inv_d.x;
-    bool neg = r.inv_d.x < 0.0f;
-    t_min = fmaxf(t_min, neg ? t1 : t0);
-    t_max = fminf(t_max, neg ? t0 : t1);
-    bool fail = t_max <= t_min;
-    t0 = (mny - r.o.y) * r.inv_d.y; t1 = (mxy - r.o.y) * r.inv_d.y;
-    neg = r.inv_d.y < 0.0f;
-    t_min = fmaxf(t_min, neg ? t1 : t0);
-    t_max = fminf(t_max, neg ? t0 : t1);
-    fail |= t_max <= t_min;
-    t0 = (mnz - r.o.z) * r.inv_d.z; t1 = (mxz - r.o.z) * r.inv_d.z;
-    neg = r.inv_d.z < 0.0f;
-    t_min = fmaxf(t_min, neg ? t1 : t0);
-    t_max = fminf(t_max, neg ? t0 : t1);
-    fail |= t_max <= t_min;
-    return !fail;
-#endif
 }
 
+// Discriminant of Sphere::hit (sphere.rs:43: b*b - a*c with c = oc.oc - r*r) — arithmetic contract, substitution 5 (r04).
+// Algebraically  b^2 - a (|oc|^2 - r^2)  =  a (r^2 - |oc - (b/a) d|^2):  the squared distance of the centre from the ray
+// instead of the difference of two numbers of size |oc|^2 a.  In fp32 the literal form loses the hit point of a small
+// sphere seen from afar: r = 10 at |oc| = 800 gives disc = 100 a +- 0.1 a, the hit point lands up to 5e-3 inside or
+// outside the surface, and a scattered ray that starts inside meets the far side of the same sphere beyond t_min = 0.001 —
+// measured against the f64 literal restatement of the reference (tests/test_gpu_f64_tolerance.py): final_scene's small
+// spheres 10 % too dark, the image mean 0.55 % low.  With this form the error of disc is relative to r^2 a:
+// the same image is within 0.003 % of the f64 mean.  Three explicit fma for l, two for |l|^2 (single roundings on both
+// sides of the parity test, like rtmi_math.h): the instruction count of the literal form.
+__device__ __forceinline__ float sphere_disc(const RayF &r, const F3 &oc, float b, float radius) {
+    const float q = b * r.inv_a;
+    const float lx = __builtin_fmaf(-q, r.d.x, oc.x), ly = __builtin_fmaf(-q, r.d.y, oc.y), lz = __builtin_fmaf(-q, r.d.z, oc.z);
+    const float l2 = __builtin_fmaf(lz, lz, __builtin_fmaf(ly, ly, lx * lx));
+    return r.a * (radius * radius - l2);
+}
 // Sphere::hit / MovingSphere::hit — src/sphere.rs:37-77, 122-164 (t only; the record is
 // built once for the closest hit in finalize_hit)
 __device__ __forceinline__ bool sphere_test(const RayF &r, F3 c, float radius, float t_min, float t_max, float &t_out) {
     F3 oc = r.o - c;
     float b = dot(oc, r.d);
-    float cc = dot(oc, oc) - radius * radius;
-    float disc = b * b - r.a * cc;
-#ifndef RTMI_BRANCHY_TESTS
+    const float disc = sphere_disc(r, oc, b, radius);
     // select form (r03): both roots are evaluated and the first one inside (t_min, t_max) is kept, as sphere.rs:44-74
     // does with two early returns; the same comparisons on the same values (sqrt of a non-positive discriminant gives
     // NaN or 0 and is masked by disc > 0), without the three nested exec-mask regions
@@ -167,16 +161,6 @@ __device__ __forceinline__ bool sphere_test(const RayF &r, F3 c, float radius, f
     const bool ok2 = pos & (t2 < t_max) & (t2 > t_min);
     t_out = ok1 ? t1 : (ok2 ? t2 : t_out);
     return ok1 | ok2;
-#else
-    if (disc > 0.0f) {
-        float sq = __builtin_sqrtf(disc);
-        float t = (-b - sq) * r.inv_a;
-        if (t < t_max && t > t_min) { t_out = t; return true; }
-        t = (-b + sq) * r.inv_a;
-        if (t < t_max && t > t_min) { t_out = t; return true; }
-    }
-    return false;
-#endif
 }
 // ConstantMedium::hit's two boundary queries (medium.rs:29-30) against ONE static sphere:
 //   boundary.hit(ray, -MAX, MAX) -> t1, then boundary.hit(ray, t1 + 0.0001, MAX) -> t2.
@@ -184,8 +168,7 @@ __device__ __forceinline__ bool sphere_test(const RayF &r, F3 c, float radius, f
 __device__ __forceinline__ void sphere_two_queries(const RayF &r, float4 A, bool &h1, float &t1, bool &h2, float &t2) {
     const F3 oc = r.o - f3(A.x, A.y, A.z);
     const float b = dot(oc, r.d);
-    const float cc = dot(oc, oc) - A.w * A.w;
-    const float disc = b * b - r.a * cc;
+    const float disc = sphere_disc(r, oc, b, A.w);
     h1 = false; h2 = false;
     if (disc > 0.0f) {
         const float sq = __builtin_sqrtf(disc);
@@ -220,21 +203,12 @@ __device__ __forceinline__ bool rect_test(float x0, float y0, float x1, float y1
     constexpr int A = P == 0 ? 1 : (P == 1 ? 2 : 0);
     constexpr int B = P == 0 ? 2 : (P == 1 ? 0 : 1);
     float t = (k - comp<K>(r.o)) * comp<K>(r.inv_d);
-#ifndef RTMI_BRANCHY_TESTS
     const float x = comp<A>(r.o) + t * comp<A>(r.d);
     const float y = comp<B>(r.o) + t * comp<B>(r.d);
     const float m = fmaxf(fmaxf(fmaxf(t_min - t, t - t_max), fmaxf(x0 - x, x - x1)), fmaxf(y0 - y, y - y1));
     if (m > 0.0f) return false;
     t_out = t;
     return true;
-#else
-    if (t < t_min || t > t_max) return false;
-    float x = comp<A>(r.o) + t * comp<A>(r.d);
-    float y = comp<B>(r.o) + t * comp<B>(r.d);
-    if (x < x0 || x > x1 || y < y0 || y > y1) return false;
-    t_out = t;
-    return true;
-#endif
 }
 __device__ __forceinline__ bool rect_test_rt(int plane, float4 A, float k, const RayF &r, float t_min, float t_max,
                                              float &t_out) {
@@ -248,7 +222,6 @@ __device__ __forceinline__ bool cube_test(float4 A, float4 B, const RayF &r, flo
                                           int &face) {
     const float ax = A.x, ay = A.y, az = A.z, bx = A.w, by = B.x, bz = B.y;
     float cl = t_max, t = 0.0f;
-#ifndef RTMI_BRANCHY_TESTS
     // select form: every face is evaluated, the closest so far and its face number move by v_cndmask (no exec-mask
     // regions); the scan order and the shrinking interval are those of the list scan, so ties resolve the same way
     int f = -1;
@@ -262,17 +235,6 @@ __device__ __forceinline__ bool cube_test(float4 A, float4 B, const RayF &r, flo
     t_out = cl;
     face = f < 0 ? 0 : f;
     return f >= 0;
-#else
-    bool any = false;
-    if (rect_test<2>(ax, ay, bx, by, bz, r, t_min, cl, t)) { cl = t; any = true; face = 0; }
-    if (rect_test<2>(ax, ay, bx, by, az, r, t_min, cl, t)) { cl = t; any = true; face = 1; }
-    if (rect_test<1>(az, ax, bz, bx, by, r, t_min, cl, t)) { cl = t; any = true; face = 2; }
-    if (rect_test<1>(az, ax, bz, bx, ay, r, t_min, cl, t)) { cl = t; any = true; face = 3; }
-    if (rect_test<0>(ay, az, by, bz, bx, r, t_min, cl, t)) { cl = t; any = true; face = 4; }
-    if (rect_test<0>(ay, az, by, bz, ax, r, t_min, cl, t)) { cl = t; any = true; face = 5; }
-    t_out = cl;
-    return any;
-#endif
 }
 
 // Instanced primitive (rtmi.h, RTMI_PRIMFLAG_XF_*): the ray of the surrounding frame taken into the primitive's own

@@ -144,9 +144,6 @@ __device__ __forceinline__ F3 tex_value_wave(const DevScene &sc, bool want, rtmi
     unsigned long long m = __ballot(noise);
     if (m != 0ull) { // wave-uniform
         float turb = 0.0f;
-#ifdef RTMI_DIAG_NO_NOISE // measurement only (wrong image): what does Perlin turbulence cost?
-        turb = 0.5f;
-#else
         if (__popcll(m) > RTMI_COOP_NOISE_MAX) {
             if (noise) turb = perlin_turb(sc.perlin + table, p, 7);
         } else {
@@ -162,7 +159,6 @@ __device__ __forceinline__ F3 tex_value_wave(const DevScene &sc, bool want, rtmi
                 if (lane == L) turb = r;
             }
         }
-#endif
         if (noise) {
             const float g = 0.5f * (1.0f + rtmi_sinf(nscale * p.x + 5.0f * turb));
             out = f3(g, g, g);
@@ -347,7 +343,13 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
                 F3 c = f3(A.x, A.y, A.z);
                 if (PM.type == RTMI_PRIM_MSPHERE) c = moving_center(A, PB, PM.inv_dt, pa.rtime);
                 hn = vdiv(hp - c, A.w); // sphere.rs:50 — outward, never face-forwarded
-                if (needs_uv) sphere_uv(hn, (ext & RTMI_EXT_UV_BOOK) != 0u, hu, hv);
+                if (needs_uv) {
+                    // the flag is re-read here, behind a compiler barrier: left alone, the constant it selects is hoisted
+                    // out of the path loop into a VGPR at kernel entry and — the 129th of 128 — spilled to scratch
+                    uint32_t ext_here = ext;
+                    asm volatile("" : "+s"(ext_here));
+                    sphere_uv(hn, (ext_here & RTMI_EXT_UV_BOOK) != 0u, hu, hv);
+                }
             } else {
                 int plane;
                 float x0, y0, x1, y1;

@@ -64,9 +64,12 @@ def test_c3_cornell_box_fullsize_against_the_f64_literal(host):
     r = compare(host, "cornell_box", nx, ny, ns, rows)
     assert r["mean_radiance_f64"] > 0.05
     # measured (MI355X, r04): see DESIGN.md §6 "Stated tolerance against the reference's f64 arithmetic"
+    # (r04: 98.5 % of the channels within 1e-4, 99.3 % within 1e-3, mean |d| 4.7e-5, max 0.045; 0.78 % of the PPM values
+    # differ, 0.38 % by more than one level, at most 10 levels; image mean 2.1e-5 relative)
     assert r["image_mean_rel_err"] <= 2e-4
-    assert r["share_within_1e-3"] >= 0.80 and r["share_within_1e-2"] >= 0.995
-    assert r["mean_abs"] <= 1e-3 and r["ppm_values_differing_by_more_than_1"] <= 0.002 and r["ppm_max_level_diff"] <= 12
+    assert r["share_within_1e-4"] >= 0.97 and r["share_within_1e-3"] >= 0.985 and r["share_within_1e-2"] >= 0.995
+    assert r["mean_abs"] <= 2e-4 and r["max_abs"] <= 0.15
+    assert r["ppm_values_differing"] <= 0.02 and r["ppm_values_differing_by_more_than_1"] <= 0.01 and r["ppm_max_level_diff"] <= 20
 
 
 def test_lit_final_scene_against_the_f64_literal(host):
