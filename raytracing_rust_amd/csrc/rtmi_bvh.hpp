@@ -139,7 +139,7 @@ __device__ __forceinline__ bool geom_query(const DevScene &sc, const rtmi_item &
     bool any = false;
     for (int k = 0; k < I.count; k++) {
         const int idx = I.first + k;
-        const int type = sc.meta[idx].type;
+        const int type = reinterpret_cast<const PrimRec *>(sc.leaf_rec + (size_t)idx * 5)->M.type;
         float t;
         int pf;
         prof_tick<PROF>(prof, 13, true);            // list primitive tests

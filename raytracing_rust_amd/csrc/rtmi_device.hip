@@ -19,6 +19,7 @@
 #include <dlfcn.h>
 #include <time.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -381,14 +382,14 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
             if (!rc) rc = upload(s, reinterpret_cast<const float4 *>(alt.data()), (size_t)d->n_alt_nodes * 8, &s->dev.nodes4);
         }
     }
-    if (!rc && d->prim_gate) { // leaf records of the gated trees: see DevScene
+    if (!rc) { // leaf records: see DevScene
         std::vector<float> lr((size_t)d->n_prims * 20, 0.0f);
         for (uint32_t i = 0; i < d->n_prims; i++) {
             float *r = &lr[(size_t)i * 20];
             memcpy(r, d->prim_a + (size_t)i * 4, 16);
             memcpy(r + 4, d->prim_b + (size_t)i * 4, 16);
             memcpy(r + 8, &d->prim_meta[i], 16);
-            memcpy(r + 12, d->prim_gate + (size_t)i * 8, 32);
+            if (d->prim_gate) memcpy(r + 12, d->prim_gate + (size_t)i * 8, 32);
         }
         rc = upload(s, reinterpret_cast<const float4 *>(lr.data()), (size_t)d->n_prims * 5, &s->dev.leaf_rec);
     }
@@ -654,10 +655,11 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     // LDS part of the traversal stack: 512 entries cover the deepest stack ever seen on the reference scenes
     // (447); deeper stacks continue in global memory (64 * (depth + 2) entries per wavefront, the bound of the
     // depth-first order), so the LDS footprint (7.7 KB per wavefront) does not depend on the tree depth
-    P.use_alt = (s->dev.gate != nullptr && s->has_alt && !(p->flags & RTMI_FLAG_REF_TREE)) ? 1u : 0u;
-    const uint32_t deepest = (P.use_alt && s->meta.alt_max_depth > s->meta.max_bvh_depth) ? s->meta.alt_max_depth : s->meta.max_bvh_depth;
+    const bool use_alt = s->dev.gate != nullptr && s->has_alt && !(p->flags & RTMI_FLAG_REF_TREE);
+    P.use_alt = use_alt ? 1u : 0u;
+    const uint32_t deepest = (use_alt && s->meta.alt_max_depth > s->meta.max_bvh_depth) ? s->meta.alt_max_depth : s->meta.max_bvh_depth;
     P.spill_cap = 64u * (deepest + 2u);
-    if (P.use_alt) { // a 4-wide visit leaves up to three pending entries per level
+    if (use_alt) { // a 4-wide visit leaves up to three pending entries per level
         const uint32_t wide = 64u * (3u * s->meta.alt_max_depth + 2u);
         if (wide > P.spill_cap) P.spill_cap = wide;
     }
@@ -665,7 +667,7 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     // one with a 512-entry LDS part
     // (lean = scenes WITHOUT any BVH: its instantiation also carries the LDS word ring of the RNG, which pays exactly
     // there, see rtmi_rng.hpp)
-    const bool ext = P.use_alt || s->meta.n_nodes != 0u || (p->flags & (1u << 11));
+    const bool ext = use_alt || s->meta.n_nodes != 0u || (p->flags & (1u << 11));
 #ifndef RTMI_COOP_CAP
 #define RTMI_COOP_CAP 512u
 #endif
@@ -689,7 +691,7 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     }
     P.spill = s->spill;
     // workgroup-cooperative traversal (rtmi_bvh_block.hpp): alternative trees only, no diagnostics build
-    const bool bcoop = coop && (p->flags & RTMI_FLAG_BLOCK_COOP) != 0u && P.use_alt != 0u && s->all_alt && !prof && !inst &&
+    const bool bcoop = coop && (p->flags & RTMI_FLAG_BLOCK_COOP) != 0u && use_alt && s->all_alt && !prof && !inst &&
                        wps_req == 0u;
     const size_t bcoop_lds = (size_t)RTMI_BLK_LDS_WORDS(RTMI_BLK_CAP) * sizeof(uint32_t);
     // (test knob bit 11: a stack so small that rounds are throttled all the time — room for 64 visits when it is full)

@@ -255,9 +255,12 @@ __device__ __forceinline__ RayF prim_frame(const rtmi_xform *xf, uint32_t flags,
 template <bool INST = true>
 __device__ __forceinline__ bool prim_test(const DevScene &sc, int type, int idx, const RayF &r0, float time,
                                           float t_min, float t_max, float &t_out, int &pf) {
-    const float4 A = sc.prim_a[idx];
-    const float4 B = sc.prim_b[idx];
-    const rtmi_prim_meta M = sc.meta[idx];
+    // planes and meta from the primitive's leaf record (one base pointer for everything the trace phase reads of a
+    // primitive: the separate plane arrays cost six more live scalar registers in a kernel that spills them)
+    const PrimRec *pr = reinterpret_cast<const PrimRec *>(sc.leaf_rec + (size_t)idx * 5);
+    const float4 A = pr->A;
+    const float4 B = pr->B;
+    const rtmi_prim_meta M = pr->M;
     RayF r = r0;
     if (INST && sc.has_prim_xf && RTMI_PRIM_HAS_XF(M.flags)) r = prim_frame(sc.xforms, M.flags, r0); // first test wave-uniform
     bool h = false;
@@ -302,9 +305,9 @@ __device__ __forceinline__ bool prim_test_vals(const DevScene &sc, int type, int
 template <bool INST = true>
 __device__ __forceinline__ bool prim_test_uniform(const DevScene &sc, int idx, const RayF &r0, float time,
                                                   float t_min, float t_max, float &t_out, int &pf) {
-    const float4 A = RTMI_UNIFORM_LOAD(float4, sc.prim_a + idx);
-    const float4 B = RTMI_UNIFORM_LOAD(float4, sc.prim_b + idx);
-    const rtmi_prim_meta M = RTMI_UNIFORM_LOAD(rtmi_prim_meta, sc.meta + idx);
+    const PrimRec PR = RTMI_UNIFORM_LOAD(PrimRec, reinterpret_cast<const PrimRec *>(sc.leaf_rec + (size_t)idx * 5));
+    const float4 A = PR.A, B = PR.B;
+    const rtmi_prim_meta M = PR.M;
     const int type = M.type;
     RayF r = r0;
     if (INST && RTMI_PRIM_HAS_XF(M.flags)) { // wave-uniform: the member of a nested list is wrapped in Traslate / Rotate

@@ -162,6 +162,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     bool queue_empty = false;
     const uint32_t k0 = P.key0, k1 = P.key1;
     const int threshold = (int)P.shade_threshold;
+    // Three scalars of the trace loop in registers of their OWN: as members of the kernel-argument block they sit in
+    // eight-register tuples, and when the allocator spills such a tuple (this kernel keeps ~100 scalars in VGPR lanes) it
+    // restores all eight registers wherever one member is read — found as 48 v_readlane per list scan for the sake of t_min.
+    // The copy through an asm statement is a live range the coalescer cannot fold back into the tuple (r04: final_scene
+    // +1.5 %, cornell_box +4 % together with the one-pointer primitive records; giving every scene POINTER its own pair
+    // the same way lost 2 % / 7 % — profiles/r04_experiments/own_sgprs_ab.log: the allocator is not to be out-guessed twice)
+    float t_min;
+    uint32_t n_items, use_alt_w;
+    asm volatile("s_mov_b32 %0, %3\n s_mov_b32 %1, %4\n s_mov_b32 %2, %5" : "=&s"(t_min), "=&s"(n_items), "=&s"(use_alt_w) : "s"(P.t_min), "s"(sc.n_items), "s"(P.use_alt));
+    const bool use_alt = use_alt_w != 0u;
 
     uint32_t oidx = 0u, ltile = 0u; // slot of this lane's path in the per-sample buffer; its local tile (SIG only)
     bool alive = false, done = false, have_hit = false, overflow = false;
@@ -200,7 +210,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             W.o = pa.ro; W.d = pa.rd;
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
-            for (uint32_t it = 0; it < sc.n_items; it++) { // executed by all 64 lanes
+            for (uint32_t it = 0; it < n_items; it++) { // executed by all 64 lanes
                 const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
                 RayF R = W;
                 if (I.xform_count > 0) { // both transforms of a chain of two in ONE scalar fetch (they follow the item record)
@@ -212,7 +222,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                     float t;
                     int pf;
-                    if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, P.use_alt != 0u, need, R, pa.rtime, P.t_min, closest, cw, t, pf, overflow, prof, slot)) {
+                    if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, need, R, pa.rtime, t_min, closest, cw, t, pf, overflow, prof, slot)) {
                         closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                     }
                     prof_time<PROF>(prof, I.kind == RTMI_ITEM_BVH ? (it == 0 ? 27 : 28) : 26, tstamp);
@@ -228,13 +238,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         h1 = false; h2 = false;
                         if (need) sphere_two_queries(R, make_float4(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0]), h1, t1, h2, t2);
                     } else {
-                        h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, P.use_alt != 0u, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
-                        h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, P.use_alt != 0u, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
+                        h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
+                        h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
                     }
                     if (need && h1 && h2) {
                         // (one square root per medium: sharing it between the media of a query measured -1.1 %,
                         // profiles/r03_experiments/wdn_shared_norm_ab.log)
-                        if (medium_sample(t1, t2, P.t_min, closest, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
+                        if (medium_sample(t1, t2, t_min, closest, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
                             closest = tm; best_item = (int)it; best_medium = true;
                         }
                     }

@@ -329,8 +329,10 @@ __device__ __forceinline__ bool shade_hit(const DevScene &sc, uint32_t max_depth
             const float4 *rec = sc.shade_prim + (size_t)idx * 4;
             const float4 A = rec[0];
             rec_mat = rec[1]; rec_t0 = rec[2]; rec_t1 = rec[3];
-            const rtmi_prim_meta PM = sc.meta[idx];
-            const float4 PB = sc.prim_b[idx]; // fetched with the rest, not after the type is known (one latency, not two)
+            // (meta and plane B from the leaf record; fetched with the rest, not after the type is known: one latency, not two)
+            const PrimRec *pr = reinterpret_cast<const PrimRec *>(sc.leaf_rec + (size_t)idx * 5);
+            const rtmi_prim_meta PM = pr->M;
+            const float4 PB = pr->B;
             F3 lo = pa.ro, ld = pa.rd;
             if (xform_count > 0) xform_ray_item(sc.xforms, xform_first, xform_count, IX0, IX1, lo, ld);
             // an instanced primitive's own chain, inside the item's frame (rtmi.h)

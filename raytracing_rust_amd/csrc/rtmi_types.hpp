@@ -48,6 +48,12 @@ static_assert(sizeof(rtmi_item) == 64 && sizeof(rtmi_xform) == 16 && sizeof(DevI
 static_assert(offsetof(rtmi_item, flags) == 12 && offsetof(rtmi_item, medium_material) == 24, "item shading words at bytes 12..27");
 static_assert(offsetof(DevItem, x0) == 64 && offsetof(DevItem, x1) == 80, "embedded transforms at bytes 64 and 80");
 
+struct PrimRec { // head of a leaf record (DevScene::leaf_rec, 80 B apart)
+    float4 A, B;
+    rtmi_prim_meta M;
+};
+static_assert(sizeof(PrimRec) == 48, "leaf record head");
+
 struct DevScene {
     const DevItem *items;
     const float4 *prim_a;
@@ -62,8 +68,9 @@ struct DevScene {
     // texture arrive with ONE dependent fetch instead of the chain prim -> material -> texture
     const float4 *shade_prim;
     const float4 *shade_mat;
-    // leaf records of the gated alternative trees (device-side layout): 5 x float4 = {plane A, plane B, meta, gate min,
-    // gate max} per primitive, so a leaf visit computes one address and touches one or two cache lines instead of five
+    // leaf records (device-side layout, every scene): 5 x float4 = {plane A, plane B, meta, gate min, gate max} per
+    // primitive (gate: zeros without prim_gate), so a leaf visit of a gated tree computes one address and touches one or
+    // two cache lines instead of five, and list scans and shading read a primitive through the same base pointer
     const float4 *leaf_rec;
     const rtmi_xform *xforms;
     const rtmi_material *mats;

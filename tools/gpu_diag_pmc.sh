@@ -2,7 +2,7 @@
 # tools/gpu_diag_pmc.sh TAG [bench args] — extra SQ / SQC counter passes (diagnostics, not the judged profile)
 TAG=${1:-diag}; shift || true
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-pass() { name=$1; shift; echo "== pmc $name"; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 bench.py $BENCH_ARGS --steps 1 --warmup 1 --no-cpu-baseline --abi-multi off > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err || echo "pmc $name failed"; }
+pass() { name=$1; shift; echo "== pmc $name"; timeout -k 10 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 bench.py $BENCH_ARGS --steps 1 --warmup 1 --no-cpu-baseline --abi-multi off --no-cold-start --no-collective-at-1 > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err || echo "pmc $name failed"; }
 BENCH_ARGS="$*"
 pass A SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAIT_INST_ANY
 pass B SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_WAIT_ANY SQ_WAIT_INST_LDS
