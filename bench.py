@@ -626,7 +626,11 @@ def main():
         # Everything below comes from the rocprofv3 PMC passes COMMITTED under profiles/ (one launch of the same kernel
         # and workload on an MI355X), not from this run: kept apart under `profiled`; only `traffic` (the contract's
         # field) is repeated at the top level.
-        pf = {"source": prof.get("source"), "hbm_bytes_per_launch": prof.get("hbm_bytes_per_launch")}
+        lib_hash = abi.load_rtmi().rtmi_build_hash().decode()
+        pf = {"source": prof.get("source"), "hbm_bytes_per_launch": prof.get("hbm_bytes_per_launch"),
+              # the committed counters belong to the build whose hash they carry; another library -> stale
+              "profiled_build": prof.get("build_hash"), "running_build": lib_hash,
+              "stale": prof.get("build_hash") != lib_hash}
         rl["traffic"] = prof.get("hbm_bytes_per_launch")
         sq = roofline.sq_fractions(prof)
         if sq:

@@ -261,6 +261,8 @@ pub struct RtmiMulti {
 extern "C" {
     pub fn rtmi_device_count() -> c_int;
     pub fn rtmi_last_error() -> *const c_char;
+    /// 16 hex digits: hash of the kernel sources, rtmi.h and the compile flags this library was built from
+    pub fn rtmi_build_hash() -> *const c_char;
     pub fn rtmi_scene_create(desc: *const RtmiSceneDesc, device: c_int, out: *mut *mut RtmiScene) -> c_int;
     pub fn rtmi_scene_destroy(scene: *mut RtmiScene);
     /// frees the per-sample buffers that destroyed handles left parked (one per device) for their successors

@@ -295,6 +295,11 @@ typedef struct rtmi_scene rtmi_scene;
 
 int rtmi_device_count(void);
 const char *rtmi_last_error(void);
+/* 16 hex digits identifying the device code of this library: a hash of its kernel sources, this header and the compile
+ * flags, taken by the in-tree build (raytracing_rust_amd/build.py).  Profiles committed under profiles/ carry the hash of
+ * the build they were taken on; a reader can tell whether counters and library belong together.  "unknown" for a library
+ * built some other way. */
+const char *rtmi_build_hash(void);
 
 /* Copies the description to `device` (hipMemcpy). */
 int rtmi_scene_create(const rtmi_scene_desc *desc, int device, rtmi_scene **out);

@@ -127,7 +127,7 @@ class Stats(C.Structure):
 
 
 # every entry point include/rtmi.h declares (tests check that the library exports them all)
-RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_release_cached", "rtmi_local_tiles",
+RTMI_SYMBOLS = ["rtmi_device_count", "rtmi_last_error", "rtmi_build_hash", "rtmi_scene_create", "rtmi_scene_destroy", "rtmi_release_cached", "rtmi_local_tiles",
                 "rtmi_render_prepare", "rtmi_render_device", "rtmi_scene_status", "rtmi_render", "rtmi_render_multi", "rtmi_multi_create",
                 "rtmi_multi_prepare", "rtmi_multi_render", "rtmi_multi_destroy", "rtmi_multi_collective", "rtmi_partial_image", "rtmi_untile",
                 "rtmi_ppm_p3", "rtmi_write_ppm", "rtmi_probe_math", "rtmi_probe_philox", "rtmi_probe_xform"]
@@ -148,6 +148,7 @@ def load_rtmi():
     vp = C.c_void_p
     lib.rtmi_device_count.restype = C.c_int
     lib.rtmi_last_error.restype = C.c_char_p
+    lib.rtmi_build_hash.restype = C.c_char_p
     lib.rtmi_scene_create.restype = C.c_int
     lib.rtmi_scene_create.argtypes = [C.POINTER(SceneDesc), C.c_int, C.POINTER(vp)]
     lib.rtmi_scene_destroy.restype = None

@@ -36,6 +36,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash(extra=None, default_sched=None):
+    """sha256 (16 hex digits) of everything that decides the device code: csrc/*, include/*.h and the compile flags.
+    Compiled into librtmi.so (rtmi_build_hash()); tools/pmc_summary.py records it with the committed counter profiles and
+    bench.py marks them stale when the library it runs is another build."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in sorted(RTMI_DEPS):
+        h.update(os.path.basename(path).encode() + b"\0")
+        h.update(open(path, "rb").read())
+    extra = os.environ.get("RTMI_EXTRA_CFLAGS", "") if extra is None else extra
+    default_sched = bool(os.environ.get("RTMI_DEFAULT_SCHED")) if default_sched is None else default_sched
+    h.update(("|".join(_COMMON_FLAGS) + "|" + extra + "|" + str(default_sched)).encode())
+    return h.hexdigest()[:16]
+
+
+_COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17"]
+
+
 def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
@@ -57,8 +76,7 @@ def build_rtmi(force=False, verbose=False):
     # translation unit of their own (csrc/rtmi_lean.hip) with the default one.
     extra = os.environ.get("RTMI_EXTRA_CFLAGS", "").split()
     sched = [] if os.environ.get("RTMI_DEFAULT_SCHED") else ["-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"]
-    common = [_hipcc(), "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-std=c++17",
-              "-I" + INCLUDE]
+    common = [_hipcc()] + _COMMON_FLAGS + ["-I" + INCLUDE, '-DRTMI_BUILD_HASH="%s"' % source_hash()]
     if verbose:
         common.insert(1, "-Rpass-analysis=kernel-resource-usage")
     # three translation units, compiled side by side: the headline kernels (rtmi_device.hip), the lean instantiations

@@ -92,6 +92,11 @@ struct rtmi_scene {
 
 extern "C" const char *rtmi_last_error(void) { return g_err.c_str(); }
 
+#ifndef RTMI_BUILD_HASH
+#define RTMI_BUILD_HASH "unknown"
+#endif
+extern "C" const char *rtmi_build_hash(void) { return RTMI_BUILD_HASH; }
+
 // Per-sample buffers outlive their handle, one per device: a destroyed handle parks its buffer here and the next
 // handle on that device takes it over when it is large enough.  Why: hipMalloc of tens of GB right after a hipFree of
 // the same size stalls for SECONDS now and then on this stack (profiles/r04_experiments/first_call_probe.log: 0.3 ms

@@ -31,6 +31,18 @@
 #define MAX_2(d) "v_max_f32 v" STR(d) ", v48, v49\n"
 #define MAXMAX(d) "v_max_f32 v" STR(d) ", v48, v49\n v_max_f32 v" STR(d) ", v" STR(d) ", v50\n"
 #define CND_E64(d) "v_cndmask_b32_e64 v" STR(d) ", v48, v49, s[22:23]\n"
+#define ADD_S(d) "v_add_f32 v" STR(d) ", s20, v48\n"
+#define SUB_S(d) "v_sub_f32 v" STR(d) ", s20, v48\n"
+#define SUBREV_S(d) "v_subrev_f32 v" STR(d) ", s20, v48\n"
+#define MUL_S(d) "v_mul_f32 v" STR(d) ", s20, v48\n"
+#define MAX_S(d) "v_max_f32 v" STR(d) ", s20, v48\n"
+#define FMA_LIT(d) "v_fma_f32 v" STR(d) ", v48, v49, 0x40490fdb\n"
+#define ADD_LIT(d) "v_add_f32 v" STR(d) ", 0x40490fdb, v48\n"
+#define MOV_S(d) "v_mov_b32 v" STR(d) ", s20\n"
+#define FMAC_S(d) "v_fmac_f32 v" STR(d) ", s20, v48\n"
+#define MADAK(d) "v_fmaak_f32 v" STR(d) ", v48, v49, 0x40490fdb\n"
+#define CMP_S(d) "v_cmp_gt_f32 vcc, s20, v48\n"
+#define SUBSUB(d) "v_sub_f32 v" STR(d) ", v48, v49\n v_sub_f32 v" STR(d) ", v" STR(d) ", v50\n"
 #define PKFMA(d) "v_pk_fma_f32 v[" STR(d) ":" STR(d) "+1], v[48:49], v[50:51], v[52:53]\n"
 
 template <int MODE>
@@ -55,6 +67,17 @@ __global__ void k(unsigned long long *out, int iters) {
         else if (MODE == 13) { REP16(asm volatile(G8(MAX_2) ::: CL);) }
         else if (MODE == 14) { REP16(asm volatile(G8(MAXMAX) ::: CL);) }
         else if (MODE == 15) { REP16(asm volatile(G8(CND_E64) ::: CL);) }
+        else if (MODE == 16) { REP16(asm volatile(G8(ADD_S) ::: CL);) }
+        else if (MODE == 17) { REP16(asm volatile(G8(SUB_S) ::: CL);) }
+        else if (MODE == 18) { REP16(asm volatile(G8(MUL_S) ::: CL);) }
+        else if (MODE == 19) { REP16(asm volatile(G8(MAX_S) ::: CL);) }
+        else if (MODE == 20) { REP16(asm volatile(G8(MADAK) ::: CL);) }
+        else if (MODE == 21) { REP16(asm volatile(G8(ADD_LIT) ::: CL);) }
+        else if (MODE == 22) { REP16(asm volatile(G8(MOV_S) ::: CL);) }
+        else if (MODE == 23) { REP16(asm volatile(G8(FMAC_S) ::: CL);) }
+        else if (MODE == 24) { REP16(asm volatile(G8(SUBREV_S) ::: CL);) }
+        else if (MODE == 25) { REP16(asm volatile(G8(CMP_S) ::: CL);) }
+        else if (MODE == 26) { REP16(asm volatile(G8(SUBSUB) ::: CL);) }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
@@ -95,5 +118,16 @@ int main() {
     run<13>("v_max_f32 d, v, v", d, p.multiProcessorCount, b, 1);
     run<14>("v_max_f32 x2 (what a max3 replaces)", d, p.multiProcessorCount, b, 2);
     run<15>("v_cndmask_b32_e64 d, v, v, s[]", d, p.multiProcessorCount, b, 1);
+    run<16>("v_add_f32 d, s, v   (VOP2, SGPR source)", d, p.multiProcessorCount, b, 1);
+    run<17>("v_sub_f32 d, s, v", d, p.multiProcessorCount, b, 1);
+    run<24>("v_subrev_f32 d, s, v", d, p.multiProcessorCount, b, 1);
+    run<18>("v_mul_f32 d, s, v", d, p.multiProcessorCount, b, 1);
+    run<23>("v_fmac_f32 d, s, v", d, p.multiProcessorCount, b, 1);
+    run<19>("v_max_f32 d, s, v", d, p.multiProcessorCount, b, 1);
+    run<25>("v_cmp_gt_f32 vcc, s, v", d, p.multiProcessorCount, b, 1);
+    run<22>("v_mov_b32 d, s", d, p.multiProcessorCount, b, 1);
+    run<21>("v_add_f32 d, literal, v", d, p.multiProcessorCount, b, 1);
+    run<20>("v_fmaak_f32 d, v, v, literal", d, p.multiProcessorCount, b, 1);
+    run<26>("v_sub_f32 x2 dependent (v, v)", d, p.multiProcessorCount, b, 2);
     return 0;
 }

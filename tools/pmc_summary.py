@@ -58,6 +58,18 @@ def sq_per_kernel(tag_dir):
     return out, files
 
 
+def build_hash():
+    """rtmi_build_hash() of the in-tree library — the one that travelled to the GPU box and produced these counters (run this
+    tool before touching csrc/ again; it refuses when the sources no longer hash to what the library carries)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from raytracing_rust_amd import abi, build
+
+    lib_hash = abi.load_rtmi().rtmi_build_hash().decode()
+    if lib_hash != build.source_hash():
+        raise SystemExit("pmc_summary: librtmi.so is build %s but the sources hash to %s — rebuild, re-profile" % (lib_hash, build.source_hash()))
+    return lib_hash
+
+
 def main():
     tag_dir, prof_dir = sys.argv[1], sys.argv[2]
     workload = sys.argv[3] if len(sys.argv) > 3 else "final_scene 1920x1080x1000spp"
@@ -84,6 +96,7 @@ def main():
         "sq": kernels[dom]["sq"] if dom else None,
         "kernels": kernels,
         "source": prof_dir,
+        "build_hash": build_hash(),
         "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes; FETCH_SIZE (KB) doubled per "
                 "MI355X_MICROARCH.md (gfx950 reports 1/2 of wide reads); HBM bytes = min over the launches of the pass; "
                 "SQ counters = chip-wide sums of the last launch of their pass, launch_ns = that launch's duration",
