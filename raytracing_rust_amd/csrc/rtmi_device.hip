@@ -580,6 +580,16 @@ extern "C" int rtmi_render_prepare(rtmi_scene *s, const rtmi_render_params *p) {
     return plan_and_reserve(s, p, ntiles_local, chunk_spp, pass_ns);
 }
 
+// (Re)allocates what a render with these parameters needs BEFORE the caller starts its event clock: an allocation of tens
+// of GB can stall the host for seconds (see g_parked), and the kernel_ms of rtmi_stats are kernel time.  The caller holds s->mu.
+static int reserve_before_clock(rtmi_scene *s, const rtmi_render_params *p) {
+    const uint32_t ntiles_local = local_tiles_of(p, p->tile_rank);
+    if (ntiles_local == 0) return RTMI_OK;
+    if (s->busy_recorded) HIP_TRY(hipEventSynchronize(s->busy)); // the buffer may be reallocated: no render may still use it
+    uint32_t chunk_spp = 0, pass_ns = 0;
+    return plan_and_reserve(s, p, ntiles_local, chunk_spp, pass_ns);
+}
+
 // the enqueue itself; the caller holds s->mu
 static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtmi_render_params *p, void *d_texels,
                                 void *stream_, rtmi_stats *stats) {
@@ -972,6 +982,7 @@ extern "C" int rtmi_render(rtmi_scene *s, const rtmi_camera *cam, const rtmi_ren
     }
     if (p.progress_fn) {
         // asynchronous launch, then wait and report progress; stats from the scene's events afterwards
+        if ((rc = reserve_before_clock(s, &p))) return rc;
         HIP_TRY(hipEventRecord(s->ev[0], s->stream));
         rc = render_device_locked(s, cam, &p, s->texels, s->stream, nullptr);
         if (rc) return rc;
@@ -1247,6 +1258,7 @@ extern "C" int rtmi_multi_render(rtmi_multi *m, const rtmi_camera *cam, const rt
         rtmi_scene *s = m->scenes[i];
         std::lock_guard<std::mutex> slock(s->mu);
         HIP_TRY(hipSetDevice(m->devices[i]));
+        if ((rc = reserve_before_clock(s, &params[i]))) return rc;
         HIP_TRY(hipEventRecord(s->ev[0], s->stream));
         if ((rc = render_device_locked(s, cam, &params[i], m->texels[i], s->stream, nullptr))) return rc;
         HIP_TRY(hipEventRecord(s->ev[1], s->stream));
