@@ -220,7 +220,12 @@ typedef struct {
 #define RTMI_FLAG_ASYNC 16u    /* per-lane state-machine kernel (experimental, kept for comparison) */
 #define RTMI_FLAG_REF_TREE 64u /* cooperative kernel: walk the reference-topology tree, not the alternative one */
 #define RTMI_FLAG_BLOCK_COOP 32768u /* experimental: the four wavefronts of a workgroup share one traversal stack
-                                * (csrc/rtmi_bvh_block.hpp); scenes whose BVH items all carry alternative trees, else ignored */
+                                * (csrc/rtmi_bvh_block.hpp); scenes whose BVH items all carry alternative trees, else ignored.
+                                * Its stack (2432 entries in LDS) has NO global-memory part: a round takes only as many
+                                * entries as its pushes fit, and a stack that cannot take one visit makes the call fail
+                                * with RTMI_ERR_DEVICE (overflow) — possible for trees whose visits keep all four children
+                                * level after level, which the default kernel (stack continued in global memory) renders.
+                                * An independent implementation for the parity tests, 23 % slower than the default. */
 /* Diagnostic knobs in the upper flag bits (results never depend on them): bits 8..10 = wavefronts per SIMD the
  * cooperative kernel is compiled for (3 or 5; default 4); bit 11 = a 256-entry LDS part of the traversal stack,
  * so that it spills to global memory all the time (tests/test_gpu_parity.py). */
