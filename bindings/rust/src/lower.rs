@@ -102,6 +102,38 @@ fn never_hit(h: &Rc<HittableDesc>) -> bool {
         _ => false,
     }
 }
+/// lower_bvh: nothing but media below (they become deferred items) — rt_host.hpp RTMI_NO_SUBTREE
+const NO_SUBTREE: i32 = i32::MIN;
+
+/// A ConstantMedium (possibly inside Traslate / Rotate / FlipNormals) as a child of a BVHNode (rt_host.cpp is_medium_child)
+fn is_medium_child(h: &Rc<HittableDesc>) -> bool {
+    let mut dummy = false;
+    matches!(&**strip_wrappers(h, &mut dummy, None), HittableDesc::ConstantMedium { .. })
+}
+/// rt_host.cpp has_prims
+fn has_prims(h: &Rc<HittableDesc>) -> bool {
+    let mut dummy = false;
+    let s = strip_flips(h, &mut dummy);
+    if let HittableDesc::Bvh { left, right, .. } = &**s {
+        return has_prims(left) || has_prims(right);
+    }
+    !is_medium_child(h)
+}
+
+/// a ConstantMedium that was a child of a BVHNode, lowered as an item of its own behind the BVH item (rt_host.hpp)
+#[derive(Clone)]
+struct PendingMedium {
+    obj: Rc<HittableDesc>,
+    gate: Aabb,
+}
+#[derive(Clone, Copy)]
+struct DeferredMedium {
+    gate: Aabb,
+    chain_first: i32,
+    chain_count: i32,
+    save_t0: bool,
+}
+
 fn contains_moving(h: &Rc<HittableDesc>) -> bool {
     let mut dummy = false;
     match &**strip_wrappers(h, &mut dummy, None) {
@@ -253,6 +285,8 @@ pub struct SceneBuilder {
     tex_ids: HashMap<*const TextureDesc, i32>,
     mat_ids: HashMap<*const MaterialDesc, i32>,
     run_item: Option<usize>,
+    /// media met as children of the BVH being lowered, in traversal order (rt_host.hpp pending_media_)
+    pending_media: Vec<PendingMedium>,
     alt_scratch: Vec<RtmiBvhNode>, // binary SAH tree of the item being lowered
     alt_forest: Vec<f64>,          // plan_collapse: [binary node][height level][slots 0..4] cheapest collapse
     alt_split: Vec<i8>,            // ... and the split that achieves it (slot 0: the node's own share-out)
@@ -262,7 +296,7 @@ pub struct SceneBuilder {
 
 impl SceneBuilder {
     pub fn new() -> Self {
-        SceneBuilder { out: FlatScene::new(), prim_box: Vec::new(), tex_ids: HashMap::new(), mat_ids: HashMap::new(), run_item: None, alt_scratch: Vec::new(), alt_forest: Vec::new(), alt_split: Vec::new(), alt_plan_levels: 1, alt_plan_height: 0 }
+        SceneBuilder { out: FlatScene::new(), prim_box: Vec::new(), tex_ids: HashMap::new(), mat_ids: HashMap::new(), run_item: None, pending_media: Vec::new(), alt_scratch: Vec::new(), alt_forest: Vec::new(), alt_split: Vec::new(), alt_plan_levels: 1, alt_plan_height: 0 }
     }
 
     // ---- textures / materials: one record per distinct object (identity = Rc pointer) ------------------------
@@ -411,6 +445,13 @@ impl SceneBuilder {
             HittableDesc::Bvh { left, right, bbox } => (left, right, bbox),
             _ => unreachable!(),
         };
+        let hp = [has_prims(left), has_prims(right)];
+        if !hp[0] && !hp[1] {
+            // nothing but media below: no node; they become deferred items
+            self.collect_media(left, bbox);
+            self.collect_media(right, bbox);
+            return Ok(NO_SUBTREE);
+        }
         if depth > self.out.max_bvh_depth {
             self.out.max_bvh_depth = depth;
         }
@@ -425,6 +466,12 @@ impl SceneBuilder {
                 me.rmin = me.lmin;
                 me.rmax = me.lmax;
                 break;
+            }
+            if !hp[c] {
+                // media only on this side: the slot repeats the sibling (right == left is legal; visited once)
+                self.collect_media(if c == 0 { left } else { right }, bbox);
+                child[c] = NO_SUBTREE;
+                continue;
             }
             let mut flip = false;
             let h = strip_flips(if c == 0 { left } else { right }, &mut flip);
@@ -458,9 +505,35 @@ impl SceneBuilder {
                 me.rmax = mx;
             }
         }
-        self.out.nodes[id].left = child[0];
-        self.out.nodes[id].right = child[1];
+        {
+            let me = &mut self.out.nodes[id];
+            if child[0] == NO_SUBTREE {
+                child[0] = child[1];
+                me.lmin = me.rmin;
+                me.lmax = me.rmax;
+            }
+            if child[1] == NO_SUBTREE {
+                child[1] = child[0];
+                me.rmin = me.lmin;
+                me.rmax = me.lmax;
+            }
+            me.left = child[0];
+            me.right = child[1];
+        }
         Ok(id as i32)
+    }
+
+    /// the media below `h` (a child of the node whose box is `parent`) in traversal order; only called for subtrees
+    /// without primitives (rt_host.cpp collect_media)
+    fn collect_media(&mut self, h: &Rc<HittableDesc>, parent: &Aabb) {
+        let mut dummy = false;
+        let s = strip_flips(h, &mut dummy);
+        if let HittableDesc::Bvh { left, right, bbox } = &**s {
+            self.collect_media(left, bbox);
+            self.collect_media(right, bbox); // the same object on both sides: evaluated, and drawn, twice
+            return;
+        }
+        self.pending_media.push(PendingMedium { obj: h.clone(), gate: *parent });
     }
 
     /// One primitive as a leaf below the reference node whose box is `holder`: its planes, its gate (that box), its
@@ -830,11 +903,24 @@ impl SceneBuilder {
 
     /// one entry of the world list: [FlipNormals][ConstantMedium][Traslate/Rotate chain] geometry
     fn lower_item(&mut self, top: &Rc<HittableDesc>) -> Result<(), LowerError> {
+        self.lower_item_deferred(top, None)
+    }
+
+    /// `deferred`: a medium that was a child of a BVHNode — it sits inside the transforms of that BVH item (a copy of them
+    /// first), is gated by the box of that node and evaluated against the t_max the BVH was entered with (rtmi.h)
+    fn lower_item_deferred(&mut self, top: &Rc<HittableDesc>, deferred: Option<DeferredMedium>) -> Result<(), LowerError> {
         let mut it = zero_item();
         it.xform_first = self.out.xforms.len() as i32;
         let (mut flip, mut medium) = (false, false);
         let mut medium_outer = 0u32;
         let mut h = top;
+        if let Some(d) = &deferred {
+            for k in 0..d.chain_count {
+                let x = self.out.xforms[(d.chain_first + k) as usize];
+                self.out.xforms.push(x);
+            }
+            it.xform_count = d.chain_count;
+        }
         loop {
             // peel wrappers, outermost first
             match &**h {
@@ -869,8 +955,37 @@ impl SceneBuilder {
             }
         }
         it.flags = (if flip { RTMI_ITEMFLAG_FLIP } else { 0 }) | (if medium { RTMI_ITEMFLAG_MEDIUM } else { 0 }) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT);
+        if let Some(d) = &deferred {
+            if !medium {
+                return Err(LowerError::Panic("lower_item: a deferred item must be a ConstantMedium".into()));
+            }
+            if d.chain_count > 15 || it.xform_count > 15 {
+                return Err(LowerError::Unsupported("ConstantMedium below a BVHNode inside more than 15 Traslate/Rotate wrappers".into()));
+            }
+            if let HittableDesc::Bvh { .. } = &**h {
+                return Err(LowerError::Unsupported("a ConstantMedium whose boundary is a BVHNode cannot itself be a child of a BVHNode".into()));
+            }
+            it.flags |= RTMI_ITEMFLAG_DEFERRED | ((d.chain_count as u32) << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) | (if d.save_t0 { RTMI_ITEMFLAG_SAVE_T0 } else { 0 });
+        }
         match &**h {
+            HittableDesc::Bvh { left, right, bbox } if !has_prims(h) => {
+                // nothing but media below: no BVH item at all, only the deferred ones
+                if medium {
+                    return Err(LowerError::Unsupported("a ConstantMedium over a BVHNode of media is not lowered".into()));
+                }
+                self.pending_media.clear();
+                self.collect_media(left, bbox);
+                self.collect_media(right, bbox);
+                let pend = std::mem::take(&mut self.pending_media);
+                self.run_item = None;
+                for (k, pm) in pend.iter().enumerate() {
+                    let dm = DeferredMedium { gate: pm.gate, chain_first: it.xform_first, chain_count: it.xform_count, save_t0: k == 0 };
+                    self.lower_item_deferred(&pm.obj, Some(dm))?;
+                }
+                return Ok(());
+            }
             HittableDesc::Bvh { bbox, .. } => {
+                self.pending_media.clear();
                 it.kind = RTMI_ITEM_BVH;
                 let (mn, mx) = put_box(bbox);
                 it.root_min = mn;
@@ -956,6 +1071,34 @@ impl SceneBuilder {
             }
         }
         self.run_item = None;
+        if let Some(d) = &deferred {
+            // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
+            let (gmn, gmx) = put_box(&d.gate);
+            for q in it.first..it.first + it.count {
+                let g = &mut self.out.prim_gate[q as usize * 8..q as usize * 8 + 8];
+                g[0] = gmn[0];
+                g[1] = gmn[1];
+                g[2] = gmn[2];
+                g[4] = gmx[0];
+                g[5] = gmx[1];
+                g[6] = gmx[2];
+            }
+        }
+        if it.kind == RTMI_ITEM_BVH && !self.pending_media.is_empty() {
+            // media that were children of this BVH: deferred items, in order
+            if medium {
+                return Err(LowerError::Unsupported("a ConstantMedium whose boundary BVHNode holds media is not lowered".into()));
+            }
+            it.flags |= RTMI_ITEMFLAG_SAVE_T0;
+            let (chain_first, chain_count) = (it.xform_first, it.xform_count);
+            self.out.items.push(it);
+            let pend = std::mem::take(&mut self.pending_media);
+            for pm in pend.iter() {
+                let dm = DeferredMedium { gate: pm.gate, chain_first, chain_count, save_t0: false };
+                self.lower_item_deferred(&pm.obj, Some(dm))?;
+            }
+            return Ok(());
+        }
         self.out.items.push(it);
         Ok(())
     }

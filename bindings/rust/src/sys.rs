@@ -4,7 +4,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTMI_ABI_VERSION: u32 = 6;
+pub const RTMI_ABI_VERSION: u32 = 7;
 pub const RTMI_FLAG_FAST_CULL: u32 = 1;
 pub const RTMI_FLAG_PATH_SIG: u32 = 2;
 pub const RTMI_FLAG_PROFILE: u32 = 4;
@@ -57,6 +57,12 @@ pub const RTMI_ITEMFLAG_FLIP: u32 = 1;
 pub const RTMI_ITEMFLAG_MEDIUM: u32 = 2;
 /// MEDIUM items: bits 8..11 = number of the item's first transforms that wrap the ConstantMedium itself
 pub const RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT: u32 = 8;
+/// a ConstantMedium that was a child of a BVHNode follows its BVH item as a DEFERRED item (rtmi.h): SAVE_T0 on the BVH item
+/// (or on the first deferred one when the BVH holds nothing but media) remembers the closest hit before it
+pub const RTMI_ITEMFLAG_SAVE_T0: u32 = 4;
+pub const RTMI_ITEMFLAG_DEFERRED: u32 = 8;
+/// DEFERRED items: bits 12..15 = number of leading transforms that belong to the enclosing BVH item
+pub const RTMI_ITEMFLAG_GATE_OUTER_SHIFT: u32 = 12;
 pub const RTMI_NO_CHILD: i32 = 0x7fff_ffff;
 
 #[repr(C)]

@@ -36,7 +36,8 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 6u /* the scene description (6: instanced primitives, rtmi_prim_meta.flags bits 4..7, 12..31) */
+#define RTMI_ABI_VERSION 7u /* the scene description (6: instanced primitives, rtmi_prim_meta.flags bits 4..7, 12..31;
+                             * 7: deferred media, RTMI_ITEMFLAG_SAVE_T0 / _DEFERRED) */
 #define RTMI_MAX_BVH_DEPTH 24u /* per-lane LDS traversal stack entries */
 #define RTMI_TILE 8u           /* a wavefront renders an 8x8 pixel tile: lane = pixel */
 #define RTMI_SAMPLE_SLOT_BYTES 12u /* per-sample radiance buffer: three fp32 per finished path (budget arithmetic of
@@ -151,6 +152,24 @@ enum { RTMI_ITEM_LIST = 0, RTMI_ITEM_BVH = 1 };
  * ray direction, the scattering point) runs on the ray as those outer wrappers hand it down, and the point and normal go
  * back through them (traslate.rs:21-22, rotate.rs:94-105).  0 = the medium is outside all transforms. */
 #define RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT 8
+/* A ConstantMedium that is a CHILD OF A BVHNode (bvh.rs:11-12 takes any Hittable).  BVHNode::hit hands both children the
+ * query's own (t_min, t_max) and keeps the closer hit (bvh.rs:70-89), so such a medium (i) is evaluated with the t_max the
+ * BVH was entered with, not with what its siblings have found, (ii) draws its random number whenever its clamped
+ * boundary interval is not empty (medium.rs:30-40), at its in-order position, (iii) is reached iff every ancestor's box
+ * passes AABB::hit — nested boxes and a monotone slab test: iff its PARENT's box passes.  The trees of the description
+ * hold primitives only; such a medium is a DEFERRED item that follows its BVH item in the list (several: in traversal
+ * order; a BVHNode over one element, bvh.rs:44-45, evaluates — and draws — twice: two items):
+ *   RTMI_ITEMFLAG_SAVE_T0   on the BVH item (or, when the BVH holds nothing but media and there is no BVH item, on the
+ *                           first deferred one): remember the closest hit so far as it stands BEFORE this item (T0);
+ *   RTMI_ITEMFLAG_DEFERRED  a MEDIUM item of kind LIST: its boundary is queried only for rays whose gate passes
+ *                           AABB::hit(t_min, T0) — the gate is prim_gate of the item's first primitive (the box of the
+ *                           BVHNode the medium was a child of), the ray is the one the FIRST G transforms of the item hand
+ *                           down (G in bits 12..15: the transforms of the enclosing BVH item, copied in front of the
+ *                           medium's own) —, its interval is clamped to T0, and its hit is accepted when closer than the
+ *                           closest hit so far (an exact tie with a primitive, of probability zero, goes to the primitive). */
+#define RTMI_ITEMFLAG_SAVE_T0 4u
+#define RTMI_ITEMFLAG_DEFERRED 8u
+#define RTMI_ITEMFLAG_GATE_OUTER_SHIFT 12
 typedef struct {
     int32_t kind;
     int32_t first;           /* LIST: first primitive | BVH: root node */

@@ -9,7 +9,7 @@ import os
 
 from . import build as _build
 
-RTMI_ABI_VERSION = 6
+RTMI_ABI_VERSION = 7
 RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT = 8  # MEDIUM items: how many of the first transforms wrap the medium itself (bits 8..11)
 RTMI_PRIMFLAG_XF_COUNT_SHIFT = 4   # instanced primitive: number of its own transforms (bits 4..7)
 RTMI_PRIMFLAG_XF_FIRST_SHIFT = 12  # ... and the index of the first one in xforms (bits 12..31)
@@ -38,7 +38,8 @@ TEX_SOLID, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
 PRIM_SPHERE, PRIM_MSPHERE, PRIM_RECT, PRIM_CUBE = 0, 1, 2, 3
 ITEM_LIST, ITEM_BVH = 0, 1
-ITEMFLAG_FLIP, ITEMFLAG_MEDIUM = 1, 2
+ITEMFLAG_FLIP, ITEMFLAG_MEDIUM, ITEMFLAG_SAVE_T0, ITEMFLAG_DEFERRED = 1, 2, 4, 8
+RTMI_ITEMFLAG_GATE_OUTER_SHIFT = 12  # DEFERRED items: how many leading transforms belong to the enclosing BVH item (bits 12..15)
 XF_TRANSLATE, XF_ROTATE_X, XF_ROTATE_Y, XF_ROTATE_Z = 0, 1, 2, 3
 
 

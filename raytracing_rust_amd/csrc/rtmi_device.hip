@@ -66,6 +66,8 @@ struct rtmi_scene {
     int slots = 0;                  // CUs x 16: resident wavefronts the render kernels are launched with
     bool has_alt = false;           // some BVH item carries an alternative tree
     bool all_alt = false;           // every BVH item does (and there is one): the workgroup-cooperative kernel can run
+    bool has_deferred = false;      // media that were children of a BVHNode (RTMI_ITEMFLAG_DEFERRED): the asynchronous
+                                    // state-machine kernel does not carry them, RTMI_FLAG_ASYNC then runs the per-lane kernel
     uint32_t last_kernel = 0;       // RTMI_KERNEL_* of the last render enqueued on this handle (rtmi_stats.kernel)
     // scratch of the blocking host API (grow-only, so a host that renders frame after frame allocates once)
     rtmi_texel *texels = nullptr;
@@ -272,6 +274,12 @@ static int validate(const rtmi_scene_desc *d) {
             return fail(RTMI_ERR_INVALID, "medium material out of range");
         if ((int32_t)((it.flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) > it.xform_count)
             return fail(RTMI_ERR_INVALID, "more outer medium transforms than the item has transforms");
+        if (it.flags & RTMI_ITEMFLAG_DEFERRED) { // a medium that was a child of a BVHNode (rtmi.h)
+            if (!(it.flags & RTMI_ITEMFLAG_MEDIUM) || it.kind != RTMI_ITEM_LIST || it.count < 1 || !d->prim_gate)
+                return fail(RTMI_ERR_INVALID, "a DEFERRED item must be a MEDIUM of kind LIST with at least one primitive, and prim_gate must be given");
+            if ((int32_t)((it.flags >> RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15u) > (int32_t)((it.flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u))
+                return fail(RTMI_ERR_INVALID, "a DEFERRED item's enclosing transforms must be among those that wrap the medium");
+        }
     }
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const rtmi_material &m = d->materials[i];
@@ -336,8 +344,9 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         // so the kernel's fused two-root boundary query needs no dependent loads of the primitive's meta and planes
         std::vector<rtmi_item> items(d->items, d->items + d->n_items);
         for (rtmi_item &it : items) {
-            it.flags &= (RTMI_ITEMFLAG_FLIP | RTMI_ITEMFLAG_MEDIUM | (15u << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT));
-            if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && it.kind == RTMI_ITEM_LIST && it.count == 1 &&
+            it.flags &= (RTMI_ITEMFLAG_FLIP | RTMI_ITEMFLAG_MEDIUM | (15u << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) | RTMI_ITEMFLAG_SAVE_T0 |
+                         RTMI_ITEMFLAG_DEFERRED | (15u << RTMI_ITEMFLAG_GATE_OUTER_SHIFT));
+            if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && !(it.flags & RTMI_ITEMFLAG_DEFERRED) && it.kind == RTMI_ITEM_LIST && it.count == 1 &&
                 d->prim_meta[it.first].type == RTMI_PRIM_SPHERE &&
                 ((d->prim_meta[it.first].flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) == 0u) {
                 // (a sphere with a transform chain of its own — ConstantMedium(HittableList[Traslate(Sphere)]) — takes the
@@ -435,7 +444,10 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         if ((d->prim_meta[i].flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) s->dev.has_prim_xf = 1u;
     s->dev.has_medium_outer = 0u;
     for (uint32_t i = 0; i < d->n_items; i++)
-        if ((d->items[i].flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) s->dev.has_medium_outer = 1u;
+        if (((d->items[i].flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) || (d->items[i].flags & (RTMI_ITEMFLAG_SAVE_T0 | RTMI_ITEMFLAG_DEFERRED)))
+            s->dev.has_medium_outer = 1u; // (deferred media ride in the same instantiations as media inside transforms)
+    for (uint32_t i = 0; i < d->n_items; i++)
+        if (d->items[i].flags & RTMI_ITEMFLAG_DEFERRED) s->has_deferred = true;
     if (hipMalloc(reinterpret_cast<void **>(&s->status), RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess ||
         hipMemset(s->status, 0, RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess) {
         rtmi_scene_destroy(s);
@@ -655,7 +667,7 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     // kernel selection: default = two-phase schedule, cooperative traversal when fast-cull is on
     // (it implements the fast-cull semantics); RTMI_FLAG_SYNC = per-lane traversal; RTMI_FLAG_ASYNC =
     // per-lane state machine (kept for comparison)
-    const bool async = (p->flags & RTMI_FLAG_ASYNC) != 0u;
+    const bool async = (p->flags & RTMI_FLAG_ASYNC) != 0u && !s->has_deferred;
     const bool coop_ok = s->meta.n_prims < (1u << 22) && s->meta.n_nodes < (1u << 25) && s->meta.n_alt_nodes < (1u << 25);
     const bool coop = fast && !sync && !async && coop_ok;
     P.status = s->status;

@@ -72,8 +72,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                 ray_derive(W);
                 closest = RTMI_FLT_MAX;
                 best_item = -1; best_pf = 0; best_medium = false;
+                float t0_saved = RTMI_FLT_MAX; // the closest hit before a BVH item whose media children follow as DEFERRED items
                 for (uint32_t it = 0; it < sc.n_items; it++) {
                     const rtmi_item I = sc.items[it].it;
+                    if (I.flags & RTMI_ITEMFLAG_SAVE_T0) t0_saved = closest;
                     RayF R = W;
                     if (I.xform_count > 0) {
                         if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
@@ -89,12 +91,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                         // ConstantMedium::hit — medium.rs:28-56
                         float t1, t2, tm;
                         int pf;
+                        // a medium that was a child of a BVHNode (rtmi.h, DEFERRED): reached through its parent's box, its
+                        // interval clamped to the t_max the BVH was entered with, accepted when closer than the tree's hit
+                        const bool dfr = (I.flags & RTMI_ITEMFLAG_DEFERRED) != 0u;
+                        const float qmax = dfr ? t0_saved : closest;
+                        if (!dfr || deferred_gate(sc, I, W, P.t_min, t0_saved)) {
                         if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, stack, t1, pf, prof, slot)) {
                             if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, stack, t2, pf, prof, slot)) {
-                                if (medium_sample(t1, t2, P.t_min, closest, medium_dir_norm(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
-                                    closest = tm; best_item = (int)it; best_medium = true;
+                                if (medium_sample(t1, t2, P.t_min, qmax, medium_dir_norm(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
+                                    if (!dfr || tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }
                                 }
                             }
+                        }
                         }
                     }
                 }
@@ -210,8 +218,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             W.o = pa.ro; W.d = pa.rd;
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
+            float t0_saved = RTMI_FLT_MAX; // INST: the closest hit before a BVH item whose media children follow as DEFERRED items
             for (uint32_t it = 0; it < n_items; it++) { // executed by all 64 lanes
                 const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
+                if (INST && (I.flags & RTMI_ITEMFLAG_SAVE_T0)) t0_saved = closest;
                 RayF R = W;
                 if (I.xform_count > 0) { // both transforms of a chain of two in ONE scalar fetch (they follow the item record)
                     struct XPair { rtmi_xform x0, x1; };
@@ -238,8 +248,18 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         h1 = false; h2 = false;
                         if (need) sphere_two_queries(R, make_float4(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0]), h1, t1, h2, t2);
                     } else {
-                        h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, need, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
-                        h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, need && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
+                        // INST: a medium that was a child of a BVHNode (rtmi.h, DEFERRED) is reached through its parent's box
+                        const bool dfr = INST && (I.flags & RTMI_ITEMFLAG_DEFERRED) != 0u; // wave-uniform
+                        bool reach = need;
+                        if (dfr) reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
+                        h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, reach, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
+                        h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, reach && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
+                        if (dfr) { // its interval ends at the t_max the BVH was entered with; its hit must beat what the tree found
+                            if (reach && h1 && h2 && medium_sample(t1, t2, t_min, t0_saved, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
+                                if (tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }
+                            }
+                            h1 = false; // done
+                        }
                     }
                     if (need && h1 && h2) {
                         // (one square root per medium: sharing it between the media of a query measured -1.1 %,

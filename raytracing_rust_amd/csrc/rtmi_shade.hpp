@@ -269,6 +269,18 @@ __device__ __forceinline__ float medium_dir_norm(const DevScene &sc, uint32_t fl
     if (!xform_ray(sc.xforms, xform_first, outer, o, d)) return __builtin_sqrtf(W.a); // translations only: same direction
     return norm(d);
 }
+// Gate of a DEFERRED medium item — a ConstantMedium that was a child of a BVHNode (rtmi.h): the box of that node, tested as
+// BVHNode::hit tests its own box (bvh.rs:71; a child is reached iff every ancestor's box passes, i.e. iff its parent's
+// does) with the ray the first G transforms of the item hand down — the transforms of the enclosing BVH item — and the
+// interval (t_min, T0) the BVH was entered with.  The box travels as the gate of the item's first primitive.
+__device__ __forceinline__ bool deferred_gate(const DevScene &sc, const rtmi_item &I, const RayF &W, float t_min, float t0) {
+    const int G = (int)((I.flags >> RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15u);
+    RayF Rg = W;
+    if (G > 0 && xform_ray(sc.xforms, I.xform_first, G, Rg.o, Rg.d)) ray_derive(Rg);
+    const float4 *rec = sc.leaf_rec + (size_t)I.first * 5;
+    const float4 g0 = rec[3], g1 = rec[4];
+    return aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, Rg, t_min, t0);
+}
 template <typename RngT>
 __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, float dn,
                                               float neg_inv_density, RngT &g, uint32_t k0, uint32_t k1, float &t_out) {

@@ -772,18 +772,61 @@ static void moving_time_range(const Hittable *h, float &lo, float &hi) {
     }
 }
 
+// ---- ConstantMedium as a child of a BVHNode (r04; bvh.rs:11-12 takes any Hittable, medium.rs:11-15) ----------------
+// BVHNode::hit hands BOTH children the query's own (t_min, t_max) and keeps the closer hit (bvh.rs:75-81).  A medium child
+// therefore (i) is evaluated with the t_max the BVH was entered with — not shrunk by what its siblings report —, (ii) draws
+// its random number whenever its clamped boundary interval is not empty, hit or no hit behind it (medium.rs:30-40), in
+// the in-order position of the traversal, (iii) is reached iff every ancestor's box passes, i.e. (nested boxes, monotone
+// slab test) iff its PARENT's box passes.  The device keeps media out of its trees: such a child is lowered as a DEFERRED
+// medium item right after the BVH item (in-order), evaluated against the saved t_max (RTMI_ITEMFLAG_SAVE_T0 on the BVH
+// item), gated by the parent's box (prim_gate of its boundary), accepted if closer than what the tree found.  A node of
+// one element (bvh.rs:44-45: left and right are the same Rc) evaluates — and draws — twice: two deferred items.
+// (An exact tie between a medium's random distance and a primitive's t is decided for the primitive: probability zero.)
+static bool is_medium_child(const Hittable *h) {
+    bool dummy = false;
+    return dynamic_cast<const ConstantMedium *>(strip_wrappers(h, dummy, nullptr)) != nullptr;
+}
+static bool has_prims(const Hittable *h) {
+    bool dummy = false;
+    const Hittable *s = strip_flips(h, dummy);
+    if (auto n = dynamic_cast<const BVHNode *>(s)) return has_prims(n->left_.get()) || has_prims(n->right_.get());
+    return !is_medium_child(h);
+}
+// the media below `h` (a child of `parent`) in traversal order; only called for subtrees without primitives
+void SceneBuilder::collect_media(const Hittable *h, const BVHNode &parent) {
+    bool dummy = false;
+    const Hittable *s = strip_flips(h, dummy);
+    if (auto n = dynamic_cast<const BVHNode *>(s)) {
+        collect_media(n->left_.get(), *n);
+        collect_media(n->right_.get(), *n); // the same object on both sides: evaluated, and drawn, twice
+        return;
+    }
+    pending_media_.push_back({h, parent.bbox_});
+}
+
 int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves, bool flip_all) {
+    const Hittable *ch[2] = {n.left_.get(), n.right_.get()};
+    const bool hp[2] = {has_prims(ch[0]), has_prims(ch[1])};
+    if (!hp[0] && !hp[1]) { // nothing but media below: no node; they become deferred items
+        collect_media(ch[0], n);
+        collect_media(ch[1], n);
+        return RTMI_NO_SUBTREE;
+    }
     if (depth > out.max_bvh_depth) out.max_bvh_depth = depth;
     const int32_t id = (int32_t)out.nodes.size();
     out.nodes.push_back(rtmi_bvh_node{});
     int32_t child[2] = {0, 0};
-    const Hittable *ch[2] = {n.left_.get(), n.right_.get()};
     for (int c = 0; c < 2; c++) {
         if (c == 1 && ch[1] == ch[0]) { // same object twice
             child[1] = child[0];
             rtmi_bvh_node &me = out.nodes[(size_t)id];
             for (int k = 0; k < 3; k++) { me.rmin[k] = me.lmin[k]; me.rmax[k] = me.lmax[k]; }
             break;
+        }
+        if (!hp[c]) { // media only on this side: the slot repeats the sibling (right == left is legal; visited once)
+            collect_media(ch[c], n);
+            child[c] = RTMI_NO_SUBTREE;
+            continue;
         }
         bool flip = false;
         const Hittable *h = strip_flips(ch[c], flip);
@@ -806,8 +849,13 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
             put_box(c == 0 ? me.lmin : me.rmin, c == 0 ? me.lmax : me.rmax, lb);
         }
     }
-    out.nodes[(size_t)id].left = child[0];
-    out.nodes[(size_t)id].right = child[1];
+    {
+        rtmi_bvh_node &me = out.nodes[(size_t)id];
+        if (child[0] == RTMI_NO_SUBTREE) { child[0] = child[1]; for (int k = 0; k < 3; k++) { me.lmin[k] = me.rmin[k]; me.lmax[k] = me.rmax[k]; } }
+        if (child[1] == RTMI_NO_SUBTREE) { child[1] = child[0]; for (int k = 0; k < 3; k++) { me.rmin[k] = me.lmin[k]; me.rmax[k] = me.lmax[k]; } }
+        me.left = child[0];
+        me.right = child[1];
+    }
     return id;
 }
 
@@ -1120,13 +1168,17 @@ int32_t SceneBuilder::collapse_alt(int32_t ref, uint32_t depth, int height) {
     return id;
 }
 
-void SceneBuilder::lower_item(const Hittable &top) {
+void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferred) {
     rtmi_item it{};
     it.alt_first = -1;
     it.xform_first = (int32_t)out.xforms.size();
     bool flip = false, medium = false;
     uint32_t medium_outer = 0;
     const Hittable *h = &top;
+    if (deferred) { // a medium that was a child of a BVHNode: it sits inside the transforms of that BVH item — a copy of them first
+        for (int k = 0; k < deferred->chain_count; k++) out.xforms.push_back(out.xforms[(size_t)(deferred->chain_first + k)]);
+        it.xform_count = deferred->chain_count;
+    }
     for (;;) { // peel wrappers, outermost first
         if (auto f = dynamic_cast<const FlipNormals *>(h)) { flip = !flip; h = f->inner().get(); continue; }
         if (auto m = dynamic_cast<const ConstantMedium *>(h)) {
@@ -1156,7 +1208,29 @@ void SceneBuilder::lower_item(const Hittable &top) {
         break;
     }
     it.flags = (flip ? RTMI_ITEMFLAG_FLIP : 0u) | (medium ? RTMI_ITEMFLAG_MEDIUM : 0u) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT);
+    if (deferred) {
+        if (!medium) throw Panic("lower_item: a deferred item must be a ConstantMedium");
+        if (deferred->chain_count > 15 || it.xform_count > 15) throw Unsupported("ConstantMedium below a BVHNode inside more than 15 Traslate/Rotate wrappers");
+        if (dynamic_cast<const BVHNode *>(h)) throw Unsupported("a ConstantMedium whose boundary is a BVHNode cannot itself be a child of a BVHNode");
+        it.flags |= RTMI_ITEMFLAG_DEFERRED | ((uint32_t)deferred->chain_count << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) |
+                    (deferred->save_t0 ? RTMI_ITEMFLAG_SAVE_T0 : 0u);
+    }
     if (auto bvh = dynamic_cast<const BVHNode *>(h)) {
+        if (!has_prims(bvh)) { // nothing but media below: no BVH item at all, only the deferred ones
+            if (medium) throw Unsupported("a ConstantMedium over a BVHNode of media is not lowered");
+            pending_media_.clear();
+            collect_media(bvh->left_.get(), *bvh);
+            collect_media(bvh->right_.get(), *bvh);
+            const std::vector<PendingMedium> pend = std::move(pending_media_);
+            pending_media_.clear();
+            run_item_ = -1;
+            for (size_t k = 0; k < pend.size(); k++) {
+                const DeferredMedium dm{pend[k].gate, it.xform_first, it.xform_count, k == 0};
+                lower_item(*pend[k].obj, &dm);
+            }
+            return;
+        }
+        pending_media_.clear();
         it.kind = RTMI_ITEM_BVH;
         put_box(it.root_min, it.root_max, bvh->bbox_);
         double scale = 0.0;
@@ -1227,6 +1301,26 @@ void SceneBuilder::lower_item(const Hittable &top) {
         it.count = 1;
     }
     run_item_ = -1;
+    if (deferred) { // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
+        float gmn[3], gmx[3];
+        put_box(gmn, gmx, deferred->gate);
+        for (int32_t q = it.first; q < it.first + it.count; q++) {
+            float *g = &out.prim_gate[(size_t)q * 8];
+            g[0] = gmn[0]; g[1] = gmn[1]; g[2] = gmn[2]; g[4] = gmx[0]; g[5] = gmx[1]; g[6] = gmx[2];
+        }
+    }
+    if (it.kind == RTMI_ITEM_BVH && !pending_media_.empty()) { // media that were children of this BVH: deferred items, in order
+        if (medium) throw Unsupported("a ConstantMedium whose boundary BVHNode holds media is not lowered");
+        it.flags |= RTMI_ITEMFLAG_SAVE_T0;
+        out.items.push_back(it);
+        const std::vector<PendingMedium> pend = std::move(pending_media_);
+        pending_media_.clear();
+        for (const PendingMedium &pm : pend) {
+            const DeferredMedium dm{pm.gate, it.xform_first, it.xform_count, false};
+            lower_item(*pm.obj, &dm);
+        }
+        return;
+    }
     out.items.push_back(it);
 }
 

@@ -350,6 +350,7 @@ struct LoweredScene {
     rtmi_scene_desc desc() const;
 };
 
+#define RTMI_NO_SUBTREE INT32_MIN /* lower_bvh: nothing but media below (they become deferred items) */
 class SceneBuilder {
   public:
     int texture_index(const Texture *t);   // lowers on first use
@@ -360,7 +361,12 @@ class SceneBuilder {
     void lower_world(const Hittable &world);
     LoweredScene out;
   private:
-    void lower_item(const Hittable &h);
+    // a ConstantMedium that was a child of a BVHNode, lowered as an item of its own behind the BVH item (rt_host.cpp)
+    struct PendingMedium { const Hittable *obj; AABB gate; };
+    struct DeferredMedium { AABB gate; int32_t chain_first; int32_t chain_count; bool save_t0; };
+    std::vector<PendingMedium> pending_media_;
+    void collect_media(const Hittable *h, const BVHNode &parent);
+    void lower_item(const Hittable &h, const DeferredMedium *deferred = nullptr);
     int push_prim(const Hittable &h, bool flip, bool force_moving);
     int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves, bool flip_all);
     int32_t lower_leaf(const Hittable &h, const BVHNode &n, bool flip, bool force_moving, double pad, bool unbounded_leaves, AABB &lb);

@@ -111,7 +111,30 @@ def random_scene(api, seed, only=None, instanced=False):
             for _ in range(n):
                 p = inst(_prim(api, rng, extent=2.5, allow_moving=moving))
                 objs.append(api.FlipNormals(p) if rng.random() < 0.1 else p)
-            if instanced and n >= 3 and rng2.random() < 0.4:
+            has_media = False
+            if instanced and rng2.random() < 0.35:
+                has_media = True
+                # ConstantMedium as a CHILD of the BVHNode (bvh.rs:11-12 takes any Hittable; tests/test_media_in_bvh.py): one to
+                # three media, around plain or transformed boundaries, sometimes themselves inside a Traslate — with n == 1
+                # and the primitive replaced, a BVH of media only
+                nm = int(rng2.integers(1, 4))
+                meds = []
+                for _ in range(nm):
+                    bq = api.Sphere(rng2.uniform(-2, 2, 3), float(rng2.uniform(0.5, 1.4)), api.Dielectric(1.5)) if rng2.random() < 0.6 \
+                        else api.Cube(rng2.uniform(-2.0, 0, 3), rng2.uniform(0.4, 1.8, 3), api.Dielectric(1.5))
+                    if rng2.random() < 0.4:
+                        bq = _wrap(api, rng2, bq, allow_flip=False)
+                    md = api.ConstantMedium(bq, float(rng2.choice([0.05, 0.4, 1.5, 5.0])), api.SolidTexture(*rng2.uniform(0.1, 0.95, 3)))
+                    if rng2.random() < 0.3:
+                        md = api.Traslate(md, rng2.uniform(-1.0, 1.0, 3))
+                    meds.append(md)
+                if n == 1 and rng2.random() < 0.5:
+                    objs = meds  # nothing but media
+                else:
+                    for md in meds:
+                        objs.insert(int(rng2.integers(0, len(objs) + 1)), md)
+                n = len(objs)
+            if instanced and n >= 3 and not has_media and rng2.random() < 0.4:
                 # a HittableList as ONE object of the BVH (bvh.rs:11-12 takes any Hittable): two to five of the objects,
                 # sometimes one of them twice (an exact tie inside the scan), sometimes with a nested list, sometimes flipped
                 k0 = int(rng2.integers(0, n - 1))
