@@ -458,6 +458,7 @@ impl SceneBuilder {
         let id = self.out.nodes.len();
         self.out.nodes.push(RtmiBvhNode { lmin: [0.0; 3], lmax: [0.0; 3], rmin: [0.0; 3], rmax: [0.0; 3], left: 0, right: 0, pad: [0; 2] });
         let mut child = [0i32; 2];
+        let pend_begin = self.pending_media.len();
         for c in 0..2 {
             if c == 1 && Rc::ptr_eq(left, right) {
                 // the same object twice (bvh.rs:44-45)
@@ -465,6 +466,13 @@ impl SceneBuilder {
                 let me = &mut self.out.nodes[id];
                 me.rmin = me.lmin;
                 me.rmax = me.lmax;
+                // the reference evaluates the object on both sides (bvh.rs:73-74): every medium below it is evaluated — and
+                // draws — a second time, after all of the first visit's
+                let pend_end = self.pending_media.len();
+                for q in pend_begin..pend_end {
+                    let pm = self.pending_media[q].clone();
+                    self.pending_media.push(pm);
+                }
                 break;
             }
             if !hp[c] {

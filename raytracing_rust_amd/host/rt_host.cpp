@@ -816,11 +816,16 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
     const int32_t id = (int32_t)out.nodes.size();
     out.nodes.push_back(rtmi_bvh_node{});
     int32_t child[2] = {0, 0};
+    const size_t pend_begin = pending_media_.size();
     for (int c = 0; c < 2; c++) {
         if (c == 1 && ch[1] == ch[0]) { // same object twice
             child[1] = child[0];
             rtmi_bvh_node &me = out.nodes[(size_t)id];
             for (int k = 0; k < 3; k++) { me.rmin[k] = me.lmin[k]; me.rmax[k] = me.lmax[k]; }
+            // the reference evaluates the object on both sides (bvh.rs:73-74): for its primitives that is the same answer
+            // twice, but every medium below it is evaluated — and draws — a second time, after all of the first visit's
+            const size_t pend_end = pending_media_.size();
+            for (size_t q = pend_begin; q < pend_end; q++) pending_media_.push_back(pending_media_[q]);
             break;
         }
         if (!hp[c]) { // media only on this side: the slot repeats the sibling (right == left is legal; visited once)

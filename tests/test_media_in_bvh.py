@@ -40,6 +40,12 @@ def world_media_in_bvh(api):
                          api.ConstantMedium(api.Traslate(api.Sphere((0.0, 0.0, 0.0), 0.45, glass), (0.4, 0.9, 0.0)), 6.0, api.SolidTexture(0.9, 0.9, 0.9))],
                         0.0, 1.0)
     w.push(api.Traslate(api.Rotate(api.AXIS_Y, outer, -30.0), (-1.0, 1.2, 3.0)))
+    # 4. a BVHNode over ONE object that is itself a BVH with a medium in it: the inner BVH is evaluated on both sides
+    # (bvh.rs:73-74), so its medium draws twice — found by the random scenes (seed 4), not by cases 1-3
+    inner2 = api.BVHNode([api.Sphere((-4.5, 1.2, 1.5), 0.5, lam(0.9, 0.5, 0.2)),
+                          api.ConstantMedium(api.Sphere((-4.2, 1.3, 1.4), 1.0, glass), 1.0, api.SolidTexture(0.4, 0.9, 0.6)),
+                          api.Cube((-5.6, 0.2, 0.8), (-5.0, 0.9, 1.6), lam(0.4, 0.4, 0.9))], 0.0, 1.0)
+    w.push(api.BVHNode([inner2], 0.0, 1.0))
     return w
 
 
@@ -57,7 +63,12 @@ def test_lowering_emits_deferred_items_in_traversal_order(host):
         outer = (it.flags >> abi.RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15
         assert g <= outer <= it.xform_count
     bvh = [k for k, it in enumerate(items) if it.kind == abi.ITEM_BVH]
-    assert len(bvh) == 2  # the BVH of media only has no BVH item
+    assert len(bvh) == 3  # the BVH of media only has no BVH item
+    tail = items[bvh[2] + 1:]  # case 4: the one medium of the inner BVH, once per side of the one-element node above it
+    assert len(tail) % 2 == 0 and len(tail) >= 2 and all(it.flags & abi.ITEMFLAG_DEFERRED for it in tail)
+    assert len({it.medium_material for it in tail}) == 1
+    items = items[:bvh[2]]
+    bvh = bvh[:2]
     for k in bvh:
         assert items[k].flags & abi.ITEMFLAG_SAVE_T0 and items[k + 1].flags & abi.ITEMFLAG_DEFERRED
     # first BVH: three media; BVHNode::new (bvh.rs:39-66) puts the odd one of a split into a node of its own, left and
