@@ -102,8 +102,9 @@ fn never_hit(h: &Rc<HittableDesc>) -> bool {
         _ => false,
     }
 }
-/// lower_bvh: nothing but media below (they become deferred items) — rt_host.hpp RTMI_NO_SUBTREE
-const NO_SUBTREE: i32 = i32::MIN;
+/// lower_bvh: nothing but media below (they become deferred items) — rt_host.hpp RTMI_NO_SUBTREE.  Not a child reference:
+/// -1 would be the leaf of type 7, primitive 2^28 - 1 (i32::MIN IS one: the sphere leaf of primitive 0)
+const NO_SUBTREE: i32 = -1;
 
 /// A ConstantMedium (possibly inside Traslate / Rotate / FlipNormals) as a child of a BVHNode (rt_host.cpp is_medium_child)
 fn is_medium_child(h: &Rc<HittableDesc>) -> bool {

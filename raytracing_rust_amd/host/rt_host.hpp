@@ -350,7 +350,8 @@ struct LoweredScene {
     rtmi_scene_desc desc() const;
 };
 
-#define RTMI_NO_SUBTREE INT32_MIN /* lower_bvh: nothing but media below (they become deferred items) */
+#define RTMI_NO_SUBTREE (-1) /* lower_bvh: nothing but media below (they become deferred items).  Not a child reference:
+                             * -1 would be the leaf of type 7, primitive 2^28 - 1 (INT32_MIN IS one: the sphere leaf of primitive 0) */
 class SceneBuilder {
   public:
     int texture_index(const Texture *t);   // lowers on first use
