@@ -194,6 +194,14 @@ def _list_leaf_world(api):
 def test_list_as_bvh_leaf_lowers_in_tie_order(host):
     a = host.lower(_list_leaf_world(host)).arrays()
     meta, mats = a["prim_meta"], a["materials"]
+    # every primitive hangs in the reference tree — primitive 0 too, whose sphere-leaf reference is 0x80000000 (the
+    # lowering once used that value as its "nothing but media below" mark and dropped the leaf: r04)
+    leaves = set()
+    for n in a["nodes"]:
+        for c in (n.left, n.right):
+            if c < 0:
+                leaves.add(c & 0x0fffffff)
+    assert leaves == set(range(len(meta)))
     emit = [tuple(round(float(x), 1) for x in (a["textures"][mats[m.material].tex].f0, a["textures"][mats[m.material].tex].f1,
                                                 a["textures"][mats[m.material].tex].f2)) for m in meta]
     types = [m.type for m in meta]
