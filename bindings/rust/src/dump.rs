@@ -73,6 +73,14 @@ mod tests {
         }
     }
     #[test]
+    fn media_in_bvh_match_the_cpp_lowering() {
+        // media as children of BVHNodes: DEFERRED items behind the BVH item, twice below a node referenced on both sides
+        if let Some(want) = golden("media_in_bvh") {
+            let got = flat_scene_bytes(&lower::lower_world(&scenes::media_in_bvh(1)).unwrap());
+            assert!(got == want, "flat media_in_bvh differs from the C++ lowering");
+        }
+    }
+    #[test]
     fn final_scene_matches_the_cpp_lowering() {
         let earth = std::fs::read(format!("{}/../../earthmap.rgb8", env!("CARGO_MANIFEST_DIR"))).ok();
         if let (Some(want), Some(earth)) = (golden("final_scene"), earth) {

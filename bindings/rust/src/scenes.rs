@@ -143,6 +143,40 @@ pub fn compositions(seed: u64) -> Rc<HittableDesc> {
     ])
 }
 
+/// ConstantMedium as a child of a BVHNode (twin of `media_in_bvh` in tools/dump_flat_scene.py; golden:
+/// tests/golden/flat_media_in_bvh.bin.gz): a BVH of primitives and media inside Traslate(Rotate(..)), a BVHNode over ONE
+/// object that is a BVH with a medium in it (evaluated on both sides), and a BVHNode over one medium (no primitives at all).
+pub fn media_in_bvh(seed: u64) -> Rc<HittableDesc> {
+    let mut s = SceneStreams::new(seed);
+    let grey = lambertian(solid_texture(0.7, 0.7, 0.7));
+    let glass = dielectric(1.5);
+    let mut objs = vec![
+        sphere([-3.0, 0.0, 0.0], 0.9, grey.clone()),
+        constant_medium(sphere([-1.0, 0.2, 0.5], 1.0, glass.clone()), 1.5, solid_texture(0.9, 0.2, 0.2)),
+        cube([0.3, -1.0, -0.8], [1.5, 0.4, 0.6], grey.clone()),
+        traslate(constant_medium(cube([0.0, 0.0, 0.0], [1.2, 1.2, 1.2], glass.clone()), 2.5, solid_texture(0.2, 0.9, 0.2)), [1.8, -0.9, 0.8]),
+        sphere([3.3, 0.1, -0.3], 0.8, grey.clone()),
+    ];
+    let mut inner_list = vec![
+        sphere([-4.5, 1.2, 1.5], 0.5, grey.clone()),
+        constant_medium(sphere([-4.2, 1.3, 1.4], 1.0, glass.clone()), 1.0, solid_texture(0.4, 0.9, 0.6)),
+        cube([-5.6, 0.2, 0.8], [-5.0, 0.9, 1.6], grey),
+    ];
+    // (construction order = the order of the scene stream's draws in the twin: inner first)
+    let inner = bvh_new(&mut inner_list, 0.0, 1.0, &mut s.backend);
+    let bvh = bvh_new(&mut objs, 0.0, 1.0, &mut s.backend);
+    let mut one_bvh = vec![inner];
+    let over_inner = bvh_new(&mut one_bvh, 0.0, 1.0, &mut s.backend);
+    let mut one_medium = vec![constant_medium(sphere([0.0, 2.6, -1.5], 0.8, glass), 1.2, solid_texture(0.9, 0.8, 0.2))];
+    let over_medium = bvh_new(&mut one_medium, 0.0, 1.0, &mut s.backend);
+    hittable_list(vec![
+        traslate(rotate(AXIS_Y, bvh, -30.0), [-1.0, 1.2, 3.0]),
+        over_inner,
+        over_medium,
+        sphere([0.0, 9.0, 0.0], 2.0, diffuse_light(solid_texture(4.0, 4.0, 4.0))),
+    ])
+}
+
 /// Camera literals of the #[test] drivers (tests/test.rs:741-752, 780-791, 819-830): (look_from, look_at, vfov);
 /// every driver uses view_up = (0,1,0), focus_dist = 10, aperture = 0.1, shutter [0,1], aspect = nx/ny (:47).
 pub fn camera_of(scene: &str) -> ([f64; 3], [f64; 3], f64) {

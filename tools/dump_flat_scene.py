@@ -7,7 +7,8 @@ bindings/rust/src/lower.rs mirrors the C++ SceneBuilder function by function and
 (no Rust toolchain).  On a machine with cargo, `rtmi::dump::flat_scene_bytes(&lower_world(&scenes::final_scene(1,
 false, earth))?)` must equal the gunzipped bytes of tests/golden/flat_final_scene.bin.gz byte for byte; likewise
 cornell_box, and `scenes::compositions(1)` (the compositions beyond the reference's own scenes: list leaves, instanced
-primitives, flipped subtrees, a medium inside transforms) against flat_compositions.bin.gz.  Format "RTMIFLT1" (little endian):
+primitives, flipped subtrees, a medium inside transforms) against flat_compositions.bin.gz, and `scenes::media_in_bvh(1)` (media as
+children of BVHNodes: deferred items) against flat_media_in_bvh.bin.gz.  Format "RTMIFLT1" (little endian):
     8 B magic | 11 x u32: n_items n_prims n_nodes n_alt_nodes n_xforms n_materials n_textures n_perlin n_images
     max_bvh_depth alt_max_depth | 2 x f32: bvh_time_lo bvh_time_hi | u64 image_bytes | u64 FNV-1a of image_data
     then the arrays of include/rtmi.h, raw, in this order: items, prim_a, prim_b, prim_meta, prim_gate, nodes,
@@ -21,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SCENES = ["cornell_box", "final_scene", "compositions"]
+SCENES = ["cornell_box", "final_scene", "compositions", "media_in_bvh"]
 
 
 def fnv1a64(data):
@@ -106,12 +107,38 @@ def compositions(api, seed=1):
     return world
 
 
+def media_in_bvh(api, seed=1):
+    """ConstantMedium as a child of a BVHNode (r04; twin of bindings/rust/src/scenes.rs `media_in_bvh`): a BVH of primitives
+    and media inside Traslate(Rotate(..)) — one medium around a plain boundary, one itself inside a Traslate —, a BVHNode
+    over ONE object that is a BVH with a medium in it (evaluated on both sides: its medium twice), and a BVHNode over one
+    medium (no primitives at all: no BVH item, the first deferred item remembers T0 itself)."""
+    api.seed_scene_rng(seed)
+    grey = api.Lambertian(api.SolidTexture(0.7, 0.7, 0.7))
+    glass = api.Dielectric(1.5)
+    objs = [api.Sphere((-3.0, 0.0, 0.0), 0.9, grey),
+            api.ConstantMedium(api.Sphere((-1.0, 0.2, 0.5), 1.0, glass), 1.5, api.SolidTexture(0.9, 0.2, 0.2)),
+            api.Cube((0.3, -1.0, -0.8), (1.5, 0.4, 0.6), grey),
+            api.Traslate(api.ConstantMedium(api.Cube((0.0, 0.0, 0.0), (1.2, 1.2, 1.2), glass), 2.5, api.SolidTexture(0.2, 0.9, 0.2)), (1.8, -0.9, 0.8)),
+            api.Sphere((3.3, 0.1, -0.3), 0.8, grey)]
+    inner = api.BVHNode([api.Sphere((-4.5, 1.2, 1.5), 0.5, grey),
+                         api.ConstantMedium(api.Sphere((-4.2, 1.3, 1.4), 1.0, glass), 1.0, api.SolidTexture(0.4, 0.9, 0.6)),
+                         api.Cube((-5.6, 0.2, 0.8), (-5.0, 0.9, 1.6), grey)], 0.0, 1.0)
+    world = api.HittableList()
+    world.push(api.Traslate(api.Rotate(api.AXIS_Y, api.BVHNode(objs, 0.0, 1.0), -30.0), (-1.0, 1.2, 3.0)))
+    world.push(api.BVHNode([inner], 0.0, 1.0))
+    world.push(api.BVHNode([api.ConstantMedium(api.Sphere((0.0, 2.6, -1.5), 0.8, glass), 1.2, api.SolidTexture(0.9, 0.8, 0.2))], 0.0, 1.0))
+    world.push(api.Sphere((0.0, 9.0, 0.0), 2.0, api.DiffuseLight(api.SolidTexture(4.0, 4.0, 4.0))))
+    return world
+
+
 def dump(name):
     from raytracing_rust_amd import Host, scenes
 
     host = Host()
     if name == "compositions":
         world = compositions(host, 1)
+    elif name == "media_in_bvh":
+        world = media_in_bvh(host, 1)
     else:
         _, world = scenes.build(host, name, 64, 64, seed=1)
     sc = host.lower(world)
