@@ -112,13 +112,25 @@ fn is_medium_child(h: &Rc<HittableDesc>) -> bool {
     matches!(&**strip_wrappers(h, &mut dummy, None), HittableDesc::ConstantMedium { .. })
 }
 /// rt_host.cpp has_prims
+/// A BVHNode inside Traslate / Rotate as a child of a BVHNode: an instanced subtree, lowered as a DEFERRED BVH item
+/// (rt_host.cpp is_instanced_bvh_child)
+fn is_instanced_bvh_child(h: &Rc<HittableDesc>) -> bool {
+    let mut dummy = false;
+    let mut chain: Vec<RtmiXform> = Vec::new();
+    let core = strip_wrappers(h, &mut dummy, Some(&mut chain));
+    matches!(&**core, HittableDesc::Bvh { .. }) && !chain.is_empty()
+}
+fn is_deferred_child(h: &Rc<HittableDesc>) -> bool {
+    is_medium_child(h) || is_instanced_bvh_child(h)
+}
+/// rt_host.cpp has_prims
 fn has_prims(h: &Rc<HittableDesc>) -> bool {
     let mut dummy = false;
     let s = strip_flips(h, &mut dummy);
     if let HittableDesc::Bvh { left, right, .. } = &**s {
         return has_prims(left) || has_prims(right);
     }
-    !is_medium_child(h)
+    !is_deferred_child(h)
 }
 
 /// a ConstantMedium that was a child of a BVHNode, lowered as an item of its own behind the BVH item (rt_host.hpp)
@@ -126,6 +138,8 @@ fn has_prims(h: &Rc<HittableDesc>) -> bool {
 struct PendingMedium {
     obj: Rc<HittableDesc>,
     gate: Aabb,
+    rank: i32,  // primitives pushed before it: its in-order position among the leaves of the enclosing tree
+    flip: bool, // FlipNormals around ancestors inside the tree
 }
 #[derive(Clone, Copy)]
 struct DeferredMedium {
@@ -133,6 +147,8 @@ struct DeferredMedium {
     chain_first: i32,
     chain_count: i32,
     save_t0: bool,
+    rank: i32,
+    flip: bool,
 }
 
 fn contains_moving(h: &Rc<HittableDesc>) -> bool {
@@ -449,8 +465,8 @@ impl SceneBuilder {
         let hp = [has_prims(left), has_prims(right)];
         if !hp[0] && !hp[1] {
             // nothing but media below: no node; they become deferred items
-            self.collect_media(left, bbox);
-            self.collect_media(right, bbox);
+            self.collect_media(left, bbox, flip_all);
+            self.collect_media(right, bbox, flip_all);
             return Ok(NO_SUBTREE);
         }
         if depth > self.out.max_bvh_depth {
@@ -478,7 +494,7 @@ impl SceneBuilder {
             }
             if !hp[c] {
                 // media only on this side: the slot repeats the sibling (right == left is legal; visited once)
-                self.collect_media(if c == 0 { left } else { right }, bbox);
+                self.collect_media(if c == 0 { left } else { right }, bbox, flip_all);
                 child[c] = NO_SUBTREE;
                 continue;
             }
@@ -534,15 +550,16 @@ impl SceneBuilder {
 
     /// the media below `h` (a child of the node whose box is `parent`) in traversal order; only called for subtrees
     /// without primitives (rt_host.cpp collect_media)
-    fn collect_media(&mut self, h: &Rc<HittableDesc>, parent: &Aabb) {
-        let mut dummy = false;
-        let s = strip_flips(h, &mut dummy);
+    fn collect_media(&mut self, h: &Rc<HittableDesc>, parent: &Aabb, flip_all: bool) {
+        let mut flip = false;
+        let s = strip_flips(h, &mut flip);
         if let HittableDesc::Bvh { left, right, bbox } = &**s {
-            self.collect_media(left, bbox);
-            self.collect_media(right, bbox); // the same object on both sides: evaluated, and drawn, twice
+            // (FlipNormals around an inner BVHNode: the flip goes down, as in lower_bvh)
+            self.collect_media(left, bbox, flip_all != flip);
+            self.collect_media(right, bbox, flip_all != flip); // the same object on both sides: evaluated, and drawn, twice
             return;
         }
-        self.pending_media.push(PendingMedium { obj: h.clone(), gate: *parent });
+        self.pending_media.push(PendingMedium { obj: h.clone(), gate: *parent, rank: self.out.prim_meta.len() as i32, flip: flip_all });
     }
 
     /// One primitive as a leaf below the reference node whose box is `holder`: its planes, its gate (that box), its
@@ -924,6 +941,7 @@ impl SceneBuilder {
         let mut medium_outer = 0u32;
         let mut h = top;
         if let Some(d) = &deferred {
+            flip = d.flip; // inside the FlipNormals around the enclosing item or around its ancestors within the tree
             for k in 0..d.chain_count {
                 let x = self.out.xforms[(d.chain_first + k) as usize];
                 self.out.xforms.push(x);
@@ -965,16 +983,23 @@ impl SceneBuilder {
         }
         it.flags = (if flip { RTMI_ITEMFLAG_FLIP } else { 0 }) | (if medium { RTMI_ITEMFLAG_MEDIUM } else { 0 }) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT);
         if let Some(d) = &deferred {
-            if !medium {
-                return Err(LowerError::Panic("lower_item: a deferred item must be a ConstantMedium".into()));
+            let is_bvh = matches!(&**h, HittableDesc::Bvh { .. });
+            if !medium && !is_bvh {
+                return Err(LowerError::Panic("lower_item: a deferred item must be a ConstantMedium or an instanced BVHNode".into()));
             }
             if d.chain_count > 15 || it.xform_count > 15 {
-                return Err(LowerError::Unsupported("ConstantMedium below a BVHNode inside more than 15 Traslate/Rotate wrappers".into()));
+                return Err(LowerError::Unsupported("a deferred child of a BVHNode inside more than 15 Traslate/Rotate wrappers".into()));
             }
-            if let HittableDesc::Bvh { .. } = &**h {
+            if medium && is_bvh {
                 return Err(LowerError::Unsupported("a ConstantMedium whose boundary is a BVHNode cannot itself be a child of a BVHNode".into()));
             }
             it.flags |= RTMI_ITEMFLAG_DEFERRED | ((d.chain_count as u32) << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) | (if d.save_t0 { RTMI_ITEMFLAG_SAVE_T0 } else { 0 });
+            if !medium {
+                // an instanced BVHNode: its gate travels in two records behind the chain (rtmi.h), before its primitives' own chains
+                let (gmn, gmx) = put_box(&d.gate);
+                self.out.xforms.push(RtmiXform { kind: RTMI_XF_GATE_MIN, x: gmn[0], y: gmn[1], z: gmn[2] });
+                self.out.xforms.push(RtmiXform { kind: RTMI_XF_GATE_MAX, x: gmx[0], y: gmx[1], z: gmx[2] });
+            }
         }
         match &**h {
             HittableDesc::Bvh { left, right, bbox } if !has_prims(h) => {
@@ -983,12 +1008,12 @@ impl SceneBuilder {
                     return Err(LowerError::Unsupported("a ConstantMedium over a BVHNode of media is not lowered".into()));
                 }
                 self.pending_media.clear();
-                self.collect_media(left, bbox);
-                self.collect_media(right, bbox);
+                self.collect_media(left, bbox, false);
+                self.collect_media(right, bbox, false);
                 let pend = std::mem::take(&mut self.pending_media);
                 self.run_item = None;
                 for (k, pm) in pend.iter().enumerate() {
-                    let dm = DeferredMedium { gate: pm.gate, chain_first: it.xform_first, chain_count: it.xform_count, save_t0: k == 0 };
+                    let dm = DeferredMedium { gate: pm.gate, chain_first: it.xform_first, chain_count: it.xform_count, save_t0: k == 0 && deferred.is_none(), rank: pm.rank, flip: pm.flip != flip };
                     self.lower_item_deferred(&pm.obj, Some(dm))?;
                 }
                 return Ok(());
@@ -1080,7 +1105,10 @@ impl SceneBuilder {
             }
         }
         self.run_item = None;
-        if let Some(d) = &deferred {
+        if let (Some(d), false) = (&deferred, medium) {
+            it.count = d.rank; // leaves of the enclosing tree that precede it in traversal order (ties)
+        }
+        if let (Some(d), true) = (&deferred, medium) {
             // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
             let (gmn, gmx) = put_box(&d.gate);
             for q in it.first..it.first + it.count {
@@ -1096,14 +1124,16 @@ impl SceneBuilder {
         if it.kind == RTMI_ITEM_BVH && !self.pending_media.is_empty() {
             // media that were children of this BVH: deferred items, in order
             if medium {
-                return Err(LowerError::Unsupported("a ConstantMedium whose boundary BVHNode holds media is not lowered".into()));
+                return Err(LowerError::Unsupported("a ConstantMedium whose boundary BVHNode holds media or instanced subtrees is not lowered".into()));
             }
-            it.flags |= RTMI_ITEMFLAG_SAVE_T0;
+            if deferred.is_none() {
+                it.flags |= RTMI_ITEMFLAG_SAVE_T0; // (a deferred BVH item's own deferred children share its group's T0)
+            }
             let (chain_first, chain_count) = (it.xform_first, it.xform_count);
             self.out.items.push(it);
             let pend = std::mem::take(&mut self.pending_media);
             for pm in pend.iter() {
-                let dm = DeferredMedium { gate: pm.gate, chain_first, chain_count, save_t0: false };
+                let dm = DeferredMedium { gate: pm.gate, chain_first, chain_count, save_t0: false, rank: pm.rank, flip: pm.flip != flip };
                 self.lower_item_deferred(&pm.obj, Some(dm))?;
             }
             return Ok(());

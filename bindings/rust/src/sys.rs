@@ -51,6 +51,9 @@ pub const RTMI_XF_TRANSLATE: i32 = 0;
 pub const RTMI_XF_ROTATE_X: i32 = 1;
 pub const RTMI_XF_ROTATE_Y: i32 = 2;
 pub const RTMI_XF_ROTATE_Z: i32 = 3;
+/// not transforms: the two records behind the chain of a DEFERRED BVH item hold its gate box
+pub const RTMI_XF_GATE_MIN: i32 = 4;
+pub const RTMI_XF_GATE_MAX: i32 = 5;
 pub const RTMI_ITEM_LIST: i32 = 0;
 pub const RTMI_ITEM_BVH: i32 = 1;
 pub const RTMI_ITEMFLAG_FLIP: u32 = 1;

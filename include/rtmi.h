@@ -133,7 +133,9 @@ typedef struct {
 #define RTMI_LEAF(type, prim) ((int32_t)(0x80000000u | ((uint32_t)(type) << 28) | (uint32_t)(prim)))
 
 /* ---- instance transforms: Traslate (src/traslate.rs), Rotate (src/rotate.rs) ---- */
-enum { RTMI_XF_TRANSLATE = 0, RTMI_XF_ROTATE_X = 1, RTMI_XF_ROTATE_Y = 2, RTMI_XF_ROTATE_Z = 3 };
+enum { RTMI_XF_TRANSLATE = 0, RTMI_XF_ROTATE_X = 1, RTMI_XF_ROTATE_Y = 2, RTMI_XF_ROTATE_Z = 3,
+       /* not transforms: the two records BEHIND the chain of a DEFERRED BVH item hold its gate box (x, y, z = min / max) */
+       RTMI_XF_GATE_MIN = 4, RTMI_XF_GATE_MAX = 5 };
 typedef struct {
     int32_t kind;
     float x, y, z; /* TRANSLATE: offset | ROTATE_*: x = sin(theta), y = cos(theta) */
@@ -166,7 +168,13 @@ enum { RTMI_ITEM_LIST = 0, RTMI_ITEM_BVH = 1 };
  *                           BVHNode the medium was a child of), the ray is the one the FIRST G transforms of the item hand
  *                           down (G in bits 12..15: the transforms of the enclosing BVH item, copied in front of the
  *                           medium's own) —, its interval is clamped to T0, and its hit is accepted when closer than the
- *                           closest hit so far (an exact tie with a primitive, of probability zero, goes to the primitive). */
+ *                           closest hit so far (an exact tie with a primitive, of probability zero, goes to the primitive).
+ * The same for a BVHNode inside Traslate / Rotate that is a child of a BVHNode (an instanced subtree; traslate.rs:6-9 and
+ * rotate.rs:21-28 wrap any Hittable): a DEFERRED item of kind BVH without the MEDIUM flag — its chain = the enclosing item's
+ * transforms, then its own; its gate box travels in the two xform records behind that chain (RTMI_XF_GATE_MIN / _MAX);
+ * its query runs with t_max = T0; `count` = the number of primitive leaves of the enclosing tree that precede it in
+ * traversal order (an exact tie with one of those goes to the subtree, with a later one to the leaf — bvh.rs:75-81: the
+ * later child wins; ties between deferred items of one group go to the later item). */
 #define RTMI_ITEMFLAG_SAVE_T0 4u
 #define RTMI_ITEMFLAG_DEFERRED 8u
 #define RTMI_ITEMFLAG_GATE_OUTER_SHIFT 12

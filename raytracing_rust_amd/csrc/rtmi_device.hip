@@ -191,7 +191,7 @@ static int validate(const rtmi_scene_desc *d) {
         if (xfc != 0u && ((uint64_t)xff + xfc > d->n_xforms)) return fail(RTMI_ERR_INVALID, "primitive transform range out of bounds");
     }
     for (uint32_t i = 0; i < d->n_xforms; i++)
-        if (d->xforms[i].kind < RTMI_XF_TRANSLATE || d->xforms[i].kind > RTMI_XF_ROTATE_Z) return fail(RTMI_ERR_INVALID, "bad transform kind");
+        if (d->xforms[i].kind < RTMI_XF_TRANSLATE || d->xforms[i].kind > RTMI_XF_GATE_MAX) return fail(RTMI_ERR_INVALID, "bad transform kind");
     for (uint32_t i = 0; i < d->n_nodes; i++) {
         const int32_t ch[2] = {d->nodes[i].left, d->nodes[i].right};
         for (int c = 0; c < 2; c++) {
@@ -274,11 +274,20 @@ static int validate(const rtmi_scene_desc *d) {
             return fail(RTMI_ERR_INVALID, "medium material out of range");
         if ((int32_t)((it.flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) > it.xform_count)
             return fail(RTMI_ERR_INVALID, "more outer medium transforms than the item has transforms");
-        if (it.flags & RTMI_ITEMFLAG_DEFERRED) { // a medium that was a child of a BVHNode (rtmi.h)
-            if (!(it.flags & RTMI_ITEMFLAG_MEDIUM) || it.kind != RTMI_ITEM_LIST || it.count < 1 || !d->prim_gate)
-                return fail(RTMI_ERR_INVALID, "a DEFERRED item must be a MEDIUM of kind LIST with at least one primitive, and prim_gate must be given");
-            if ((int32_t)((it.flags >> RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15u) > (int32_t)((it.flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u))
-                return fail(RTMI_ERR_INVALID, "a DEFERRED item's enclosing transforms must be among those that wrap the medium");
+        for (int32_t k = 0; k < it.xform_count; k++) // (the gate records are no transforms: never inside a chain)
+            if (d->xforms[it.xform_first + k].kind > RTMI_XF_ROTATE_Z) return fail(RTMI_ERR_INVALID, "a gate record inside an item's transform chain");
+        if (it.flags & RTMI_ITEMFLAG_DEFERRED) { // a medium or an instanced subtree that was a child of a BVHNode (rtmi.h)
+            const int32_t G = (int32_t)((it.flags >> RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15u);
+            if (it.flags & RTMI_ITEMFLAG_MEDIUM) {
+                if (it.kind != RTMI_ITEM_LIST || it.count < 1 || !d->prim_gate)
+                    return fail(RTMI_ERR_INVALID, "a DEFERRED medium must be of kind LIST with at least one primitive, and prim_gate must be given");
+                if (G > (int32_t)((it.flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u))
+                    return fail(RTMI_ERR_INVALID, "a DEFERRED medium's enclosing transforms must be among those that wrap the medium");
+            } else {
+                if (it.kind != RTMI_ITEM_BVH || G > it.xform_count || (uint32_t)(it.xform_first + it.xform_count) + 2u > d->n_xforms ||
+                    d->xforms[it.xform_first + it.xform_count].kind != RTMI_XF_GATE_MIN || d->xforms[it.xform_first + it.xform_count + 1].kind != RTMI_XF_GATE_MAX)
+                    return fail(RTMI_ERR_INVALID, "a DEFERRED item without the MEDIUM flag must be of kind BVH with its two gate records behind its transform chain");
+            }
         }
     }
     for (uint32_t i = 0; i < d->n_materials; i++) {

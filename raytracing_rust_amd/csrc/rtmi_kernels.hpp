@@ -72,10 +72,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                 ray_derive(W);
                 closest = RTMI_FLT_MAX;
                 best_item = -1; best_pf = 0; best_medium = false;
-                float t0_saved = RTMI_FLT_MAX; // the closest hit before a BVH item whose media children follow as DEFERRED items
+                float t0_saved = RTMI_FLT_MAX; // the closest hit before a BVH item whose media / instanced-subtree children follow as DEFERRED items
+                int grp_first = 0x7fffffff;    // ... the index of that item (or of the first deferred one), and whether it is the enclosing tree
+                bool grp_tree = false;
                 for (uint32_t it = 0; it < sc.n_items; it++) {
                     const rtmi_item I = sc.items[it].it;
-                    if (I.flags & RTMI_ITEMFLAG_SAVE_T0) t0_saved = closest;
+                    if (I.flags & RTMI_ITEMFLAG_SAVE_T0) {
+                        t0_saved = closest; grp_first = (int)it; grp_tree = I.kind == RTMI_ITEM_BVH && !(I.flags & RTMI_ITEMFLAG_DEFERRED);
+                    }
                     RayF R = W;
                     if (I.xform_count > 0) {
                         if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
@@ -84,7 +88,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                     if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                         float t;
                         int pf;
-                        if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, P.t_min, closest, stack, t, pf, prof, slot)) {
+                        if (I.flags & RTMI_ITEMFLAG_DEFERRED) { // an instanced subtree that was a child of a BVHNode (rtmi.h)
+                            if (deferred_gate(sc, I, W, P.t_min, t0_saved) &&
+                                geom_query<FAST, PROF>(sc, I, R, pa.rtime, P.t_min, t0_saved, stack, t, pf, prof, slot) &&
+                                deferred_bvh_wins(I, t, closest, best_item, best_pf, grp_first, grp_tree)) {
+                                closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
+                            }
+                        } else if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, P.t_min, closest, stack, t, pf, prof, slot)) {
                             closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                         }
                     } else {
@@ -218,10 +228,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             W.o = pa.ro; W.d = pa.rd;
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
-            float t0_saved = RTMI_FLT_MAX; // INST: the closest hit before a BVH item whose media children follow as DEFERRED items
+            float t0_saved = RTMI_FLT_MAX; // INST: the closest hit before a BVH item whose media / instanced-subtree children follow as DEFERRED items
+            int grp_first = 0x7fffffff;    // ... the index of that item (or of the first deferred one), and whether it is the enclosing tree
+            bool grp_tree = false;
             for (uint32_t it = 0; it < n_items; it++) { // executed by all 64 lanes
                 const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
-                if (INST && (I.flags & RTMI_ITEMFLAG_SAVE_T0)) t0_saved = closest;
+                if (INST && (I.flags & RTMI_ITEMFLAG_SAVE_T0)) {
+                    t0_saved = closest; grp_first = (int)it; grp_tree = I.kind == RTMI_ITEM_BVH && !(I.flags & RTMI_ITEMFLAG_DEFERRED);
+                }
                 RayF R = W;
                 if (I.xform_count > 0) { // both transforms of a chain of two in ONE scalar fetch (they follow the item record)
                     struct XPair { rtmi_xform x0, x1; };
@@ -232,6 +246,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                     float t;
                     int pf;
+                    if (INST && (I.flags & RTMI_ITEMFLAG_DEFERRED)) { // wave-uniform: an instanced subtree that was a child of a BVHNode (rtmi.h)
+                        const bool reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
+                        if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, reach, R, pa.rtime, t_min, t0_saved, cw, t, pf, overflow, prof, slot) &&
+                            deferred_bvh_wins(I, t, closest, best_item, best_pf, grp_first, grp_tree)) {
+                            closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
+                        }
+                    } else
                     if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, need, R, pa.rtime, t_min, closest, cw, t, pf, overflow, prof, slot)) {
                         closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                     }

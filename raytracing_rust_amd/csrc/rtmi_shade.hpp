@@ -277,9 +277,27 @@ __device__ __forceinline__ bool deferred_gate(const DevScene &sc, const rtmi_ite
     const int G = (int)((I.flags >> RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15u);
     RayF Rg = W;
     if (G > 0 && xform_ray(sc.xforms, I.xform_first, G, Rg.o, Rg.d)) ray_derive(Rg);
-    const float4 *rec = sc.leaf_rec + (size_t)I.first * 5;
-    const float4 g0 = rec[3], g1 = rec[4];
+    float4 g0, g1;
+    if (I.flags & RTMI_ITEMFLAG_MEDIUM) { // a medium: the gate of its first boundary primitive
+        const float4 *rec = sc.leaf_rec + (size_t)I.first * 5;
+        g0 = rec[3]; g1 = rec[4];
+    } else { // an instanced BVHNode: the two records behind its chain ({kind, x, y, z})
+        const float4 *rec = reinterpret_cast<const float4 *>(sc.xforms + I.xform_first + I.xform_count);
+        g0 = make_float4(rec[0].y, rec[0].z, rec[0].w, 0.0f); g1 = make_float4(rec[1].y, rec[1].z, rec[1].w, 0.0f);
+    }
     return aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, Rg, t_min, t0);
+}
+// A hit of a DEFERRED BVH item (an instanced subtree that was a child of a BVHNode) against the closest hit so far: the
+// fold of bvh.rs:75-81 — closer wins, an exact tie goes to the LATER child — between the subtree (position: I.count leaves
+// of the enclosing tree precede it) and whatever holds the closest hit: something before the group (the list scan accepts
+// every hit its t_max lets through, hittable.rs:40-44), a leaf of the enclosing tree (later iff its index >= I.count), or
+// an earlier deferred item of the group (earlier).
+__device__ __forceinline__ bool deferred_bvh_wins(const rtmi_item &I, float t, float closest, int best_item, int best_pf, int grp_first,
+                                                  bool grp_tree) {
+    if (t < closest) return true;
+    if (t != closest) return false;
+    if (grp_tree && best_item == grp_first) return (best_pf >> 3) < I.count; // a leaf of the enclosing tree holds the closest hit
+    return true; // something before the group, or an earlier deferred item of it
 }
 template <typename RngT>
 __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, float dn,

@@ -786,30 +786,42 @@ static bool is_medium_child(const Hittable *h) {
     bool dummy = false;
     return dynamic_cast<const ConstantMedium *>(strip_wrappers(h, dummy, nullptr)) != nullptr;
 }
+// A BVHNode inside Traslate / Rotate as a child of a BVHNode — an instanced subtree (traslate.rs:6-9, rotate.rs:21-28 wrap
+// any Hittable).  Like a medium child it receives the query's own (t_min, t_max) and is reached iff its parent's box passes;
+// it is lowered as a DEFERRED BVH item behind the enclosing BVH item (rtmi.h): transforms = the enclosing item's, then its
+// own; gate = the parent's box in the two xform records behind its chain; query with t_max = T0.  (FlipNormals alone
+// around an inner BVHNode stays in the tree: the flip goes down to the primitives.)
+static bool is_instanced_bvh_child(const Hittable *h) {
+    bool dummy = false;
+    std::vector<rtmi_xform> chain;
+    const Hittable *core = strip_wrappers(h, dummy, &chain);
+    return dynamic_cast<const BVHNode *>(core) != nullptr && !chain.empty();
+}
+static bool is_deferred_child(const Hittable *h) { return is_medium_child(h) || is_instanced_bvh_child(h); }
 static bool has_prims(const Hittable *h) {
     bool dummy = false;
     const Hittable *s = strip_flips(h, dummy);
     if (auto n = dynamic_cast<const BVHNode *>(s)) return has_prims(n->left_.get()) || has_prims(n->right_.get());
-    return !is_medium_child(h);
+    return !is_deferred_child(h);
 }
 // the media below `h` (a child of `parent`) in traversal order; only called for subtrees without primitives
-void SceneBuilder::collect_media(const Hittable *h, const BVHNode &parent) {
-    bool dummy = false;
-    const Hittable *s = strip_flips(h, dummy);
-    if (auto n = dynamic_cast<const BVHNode *>(s)) {
-        collect_media(n->left_.get(), *n);
-        collect_media(n->right_.get(), *n); // the same object on both sides: evaluated, and drawn, twice
+void SceneBuilder::collect_media(const Hittable *h, const BVHNode &parent, bool flip_all) {
+    bool flip = false;
+    const Hittable *s = strip_flips(h, flip);
+    if (auto n = dynamic_cast<const BVHNode *>(s)) { // (FlipNormals around an inner BVHNode: the flip goes down, as in lower_bvh)
+        collect_media(n->left_.get(), *n, flip_all != flip);
+        collect_media(n->right_.get(), *n, flip_all != flip); // the same object on both sides: evaluated, and drawn, twice
         return;
     }
-    pending_media_.push_back({h, parent.bbox_});
+    pending_media_.push_back({h, parent.bbox_, (int32_t)out.prim_meta.size(), flip_all});
 }
 
 int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves, bool flip_all) {
     const Hittable *ch[2] = {n.left_.get(), n.right_.get()};
     const bool hp[2] = {has_prims(ch[0]), has_prims(ch[1])};
     if (!hp[0] && !hp[1]) { // nothing but media below: no node; they become deferred items
-        collect_media(ch[0], n);
-        collect_media(ch[1], n);
+        collect_media(ch[0], n, flip_all);
+        collect_media(ch[1], n, flip_all);
         return RTMI_NO_SUBTREE;
     }
     if (depth > out.max_bvh_depth) out.max_bvh_depth = depth;
@@ -829,7 +841,7 @@ int32_t SceneBuilder::lower_bvh(const BVHNode &n, uint32_t depth, bool force_mov
             break;
         }
         if (!hp[c]) { // media only on this side: the slot repeats the sibling (right == left is legal; visited once)
-            collect_media(ch[c], n);
+            collect_media(ch[c], n, flip_all);
             child[c] = RTMI_NO_SUBTREE;
             continue;
         }
@@ -1180,7 +1192,8 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
     bool flip = false, medium = false;
     uint32_t medium_outer = 0;
     const Hittable *h = &top;
-    if (deferred) { // a medium that was a child of a BVHNode: it sits inside the transforms of that BVH item — a copy of them first
+    if (deferred) { // a child of a BVHNode lowered as an item: it sits inside the transforms of that BVH item — a copy of them first —
+        flip = deferred->flip; // ... and inside the FlipNormals around that item or around its ancestors within the tree
         for (int k = 0; k < deferred->chain_count; k++) out.xforms.push_back(out.xforms[(size_t)(deferred->chain_first + k)]);
         it.xform_count = deferred->chain_count;
     }
@@ -1214,23 +1227,32 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
     }
     it.flags = (flip ? RTMI_ITEMFLAG_FLIP : 0u) | (medium ? RTMI_ITEMFLAG_MEDIUM : 0u) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT);
     if (deferred) {
-        if (!medium) throw Panic("lower_item: a deferred item must be a ConstantMedium");
-        if (deferred->chain_count > 15 || it.xform_count > 15) throw Unsupported("ConstantMedium below a BVHNode inside more than 15 Traslate/Rotate wrappers");
-        if (dynamic_cast<const BVHNode *>(h)) throw Unsupported("a ConstantMedium whose boundary is a BVHNode cannot itself be a child of a BVHNode");
+        const bool is_bvh = dynamic_cast<const BVHNode *>(h) != nullptr;
+        if (!medium && !is_bvh) throw Panic("lower_item: a deferred item must be a ConstantMedium or an instanced BVHNode");
+        if (deferred->chain_count > 15 || it.xform_count > 15) throw Unsupported("a deferred child of a BVHNode inside more than 15 Traslate/Rotate wrappers");
+        if (medium && is_bvh) throw Unsupported("a ConstantMedium whose boundary is a BVHNode cannot itself be a child of a BVHNode");
         it.flags |= RTMI_ITEMFLAG_DEFERRED | ((uint32_t)deferred->chain_count << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) |
                     (deferred->save_t0 ? RTMI_ITEMFLAG_SAVE_T0 : 0u);
+        if (!medium) { // an instanced BVHNode: its gate travels in two records behind the chain (rtmi.h), before its primitives' own chains
+            float gmn[3], gmx[3];
+            put_box(gmn, gmx, deferred->gate);
+            rtmi_xform g0{}, g1{};
+            g0.kind = RTMI_XF_GATE_MIN; g0.x = gmn[0]; g0.y = gmn[1]; g0.z = gmn[2];
+            g1.kind = RTMI_XF_GATE_MAX; g1.x = gmx[0]; g1.y = gmx[1]; g1.z = gmx[2];
+            out.xforms.push_back(g0); out.xforms.push_back(g1);
+        }
     }
     if (auto bvh = dynamic_cast<const BVHNode *>(h)) {
         if (!has_prims(bvh)) { // nothing but media below: no BVH item at all, only the deferred ones
             if (medium) throw Unsupported("a ConstantMedium over a BVHNode of media is not lowered");
             pending_media_.clear();
-            collect_media(bvh->left_.get(), *bvh);
-            collect_media(bvh->right_.get(), *bvh);
+            collect_media(bvh->left_.get(), *bvh, false);
+            collect_media(bvh->right_.get(), *bvh, false);
             const std::vector<PendingMedium> pend = std::move(pending_media_);
             pending_media_.clear();
             run_item_ = -1;
             for (size_t k = 0; k < pend.size(); k++) {
-                const DeferredMedium dm{pend[k].gate, it.xform_first, it.xform_count, k == 0};
+                const DeferredMedium dm{pend[k].gate, it.xform_first, it.xform_count, k == 0 && !deferred, pend[k].rank, pend[k].flip != flip};
                 lower_item(*pend[k].obj, &dm);
             }
             return;
@@ -1306,7 +1328,8 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
         it.count = 1;
     }
     run_item_ = -1;
-    if (deferred) { // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
+    if (deferred && !medium) it.count = deferred->rank; // leaves of the enclosing tree that precede it in traversal order (ties)
+    if (deferred && medium) { // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
         float gmn[3], gmx[3];
         put_box(gmn, gmx, deferred->gate);
         for (int32_t q = it.first; q < it.first + it.count; q++) {
@@ -1315,13 +1338,13 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
         }
     }
     if (it.kind == RTMI_ITEM_BVH && !pending_media_.empty()) { // media that were children of this BVH: deferred items, in order
-        if (medium) throw Unsupported("a ConstantMedium whose boundary BVHNode holds media is not lowered");
-        it.flags |= RTMI_ITEMFLAG_SAVE_T0;
+        if (medium) throw Unsupported("a ConstantMedium whose boundary BVHNode holds media or instanced subtrees is not lowered");
+        if (!deferred) it.flags |= RTMI_ITEMFLAG_SAVE_T0; // (a deferred BVH item's own deferred children share its group's T0)
         out.items.push_back(it);
         const std::vector<PendingMedium> pend = std::move(pending_media_);
         pending_media_.clear();
         for (const PendingMedium &pm : pend) {
-            const DeferredMedium dm{pm.gate, it.xform_first, it.xform_count, false};
+            const DeferredMedium dm{pm.gate, it.xform_first, it.xform_count, false, pm.rank, pm.flip != flip};
             lower_item(*pm.obj, &dm);
         }
         return;

@@ -363,10 +363,10 @@ class SceneBuilder {
     LoweredScene out;
   private:
     // a ConstantMedium that was a child of a BVHNode, lowered as an item of its own behind the BVH item (rt_host.cpp)
-    struct PendingMedium { const Hittable *obj; AABB gate; };
-    struct DeferredMedium { AABB gate; int32_t chain_first; int32_t chain_count; bool save_t0; };
+    struct PendingMedium { const Hittable *obj; AABB gate; int32_t rank; bool flip; }; // rank: primitives pushed before it (in-order position)
+    struct DeferredMedium { AABB gate; int32_t chain_first; int32_t chain_count; bool save_t0; int32_t rank; bool flip; };
     std::vector<PendingMedium> pending_media_;
-    void collect_media(const Hittable *h, const BVHNode &parent);
+    void collect_media(const Hittable *h, const BVHNode &parent, bool flip_all);
     void lower_item(const Hittable &h, const DeferredMedium *deferred = nullptr);
     int push_prim(const Hittable &h, bool flip, bool force_moving);
     int32_t lower_bvh(const BVHNode &n, uint32_t depth, bool force_moving, double pad, bool unbounded_leaves, bool flip_all);

@@ -155,6 +155,10 @@ def random_scene(api, seed, only=None, instanced=False):
                 inner = api.BVHNode(objs[:half], 0.0, 1.0)
                 if instanced and rng2.random() < 0.5:
                     inner = api.FlipNormals(inner)  # hittable.rs:67-88 around a subtree: every normal below is negated
+                if instanced and rng2.random() < 0.4:
+                    # an INSTANCED subtree: Traslate / Rotate (/ FlipNormals) around the inner BVHNode (traslate.rs:6-9 and
+                    # rotate.rs:21-28 wrap any Hittable) — a deferred BVH item behind the enclosing one (tests/test_media_in_bvh.py)
+                    inner = _wrap(api, rng2, api.Traslate(inner, rng2.uniform(-1.0, 1.0, 3)))
                 objs = [inner] + objs[half:]
             world.push(_wrap(api, rng, api.BVHNode(objs, 0.0, 1.0)))
         else:  # a participating medium inside a (transformed) boundary; FlipNormals outside only

@@ -104,9 +104,13 @@ def test_unsupported_nesting_fails_loudly(host):
         host.lower(host.ConstantMedium(inner, 0.2, tex))  # nested media
     # (an instanced PRIMITIVE as a BVH leaf lowers since r03: tests/test_random_scenes.py)
     sub = host.BVHNode([host.Sphere((0, 0, 0), 1.0, mat), host.Sphere((0, 2, 0), 1.0, mat)], 0.0, 1.0)
+    # (an instanced BVHNode as a child of a BVHNode lowers since r04, as a DEFERRED BVH item with its gate records behind its chain)
     nested = host.BVHNode([host.Traslate(sub, (1, 0, 0)), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0)
-    with pytest.raises(Unsupported):
-        host.lower(nested)  # an instanced BVH as a BVH leaf
+    c = host.lower(nested).arrays()
+    assert [it.kind for it in c["items"]] == [abi.ITEM_BVH, abi.ITEM_BVH] and c["items"][0].flags & abi.ITEMFLAG_SAVE_T0
+    d1 = c["items"][1]
+    assert d1.flags & abi.ITEMFLAG_DEFERRED and not (d1.flags & abi.ITEMFLAG_MEDIUM) and d1.xform_count == 1
+    assert [c["xforms"][d1.xform_first + k].kind for k in range(3)] == [abi.XF_TRANSLATE, abi.XF_GATE_MIN, abi.XF_GATE_MAX]
     # (a medium as a child of a BVHNode lowers since r04, as a DEFERRED item behind the BVH item: tests/test_media_in_bvh.py)
     b = host.lower(host.BVHNode([host.Traslate(inner, (1, 0, 0)), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0)).arrays()
     assert [bool(it.flags & abi.ITEMFLAG_DEFERRED) for it in b["items"]] == [False, True] and b["items"][0].flags & abi.ITEMFLAG_SAVE_T0

@@ -49,6 +49,32 @@ def world_media_in_bvh(api):
     return w
 
 
+def world_instanced_subtrees(api):
+    """A BVHNode inside Traslate / Rotate as a child of a BVHNode (an instanced subtree): alone, twice under a one-element
+    node, nested in another instanced subtree, flipped, with a medium and an instanced primitive inside, and the whole
+    thing inside an item transform."""
+    api.seed_scene_rng(7)
+    lam = lambda r, g, b: api.Lambertian(api.SolidTexture(r, g, b))  # noqa: E731
+    glass = api.Dielectric(1.5)
+    w = api.HittableList()
+    w.push(api.Rect(api.PLANE_ZX, -9.0, -9.0, 9.0, 9.0, -1.0, lam(0.6, 0.6, 0.6)))
+    w.push(api.Sphere((0.0, 10.0, 2.0), 3.0, api.DiffuseLight(api.SolidTexture(5.0, 5.0, 5.0))))
+    cluster = lambda col: api.BVHNode([api.Sphere((0.0, 0.0, 0.0), 0.45, lam(*col)), api.Cube((0.5, -0.4, -0.4), (1.2, 0.4, 0.4), lam(0.8, 0.8, 0.8)),  # noqa: E731
+                                       api.Sphere((0.3, 0.8, 0.1), 0.35, api.Metal(api.SolidTexture(0.9, 0.9, 0.9), 0.05)),
+                                       api.Rotate(api.AXIS_Z, api.Cube((-1.0, -0.3, -0.3), (-0.5, 0.3, 0.3), lam(0.3, 0.7, 0.9)), 20.0)], 0.0, 1.0)
+    deep = api.BVHNode([api.Traslate(cluster((0.9, 0.9, 0.2)), (0.0, 1.6, 0.0)), api.Sphere((0.0, 0.0, 0.0), 0.4, lam(0.9, 0.3, 0.9)),
+                        api.ConstantMedium(api.Sphere((0.8, 0.4, 0.0), 0.6, glass), 2.0, api.SolidTexture(0.3, 0.9, 0.5))], 0.0, 1.0)
+    objs = [
+        api.Sphere((-4.0, 0.0, 0.0), 0.9, lam(0.8, 0.3, 0.3)),
+        api.Traslate(api.Rotate(api.AXIS_Y, cluster((0.9, 0.2, 0.2)), 35.0), (-1.5, 0.0, 0.5)),
+        api.Cube((0.8, -1.0, -0.6), (1.8, 0.2, 0.6), lam(0.3, 0.8, 0.3)),
+        api.FlipNormals(api.Rotate(api.AXIS_X, api.Traslate(deep, (3.6, 0.2, 0.0)), 10.0)),
+        api.BVHNode([api.Traslate(cluster((0.2, 0.9, 0.9)), (-2.8, 1.9, -1.2))], 0.0, 1.0),  # a one-element node over an instanced subtree: twice
+    ]
+    w.push(api.Traslate(api.Rotate(api.AXIS_Y, api.BVHNode(objs, 0.0, 1.0), -15.0), (0.3, 0.2, 1.0)))
+    return w
+
+
 def camera(api, nx, ny):
     return api.Camera((1.0, 3.0, 9.0), (0.0, 0.6, 0.5), (0.0, 1.0, 0.0), 42.0, nx / ny, 0.05, 9.0, 0.0, 1.0)
 
@@ -103,8 +129,41 @@ def test_mirror_equals_f64_oracle(host, orc64):
     orc64.free_all()
 
 
+def test_instanced_subtrees_lower_as_deferred_bvh_items(host):
+    a = host.lower(world_instanced_subtrees(host)).arrays()
+    items = a["items"]
+    bvh = [it for it in items if it.kind == abi.ITEM_BVH]
+    dfr = [it for it in bvh if it.flags & abi.ITEMFLAG_DEFERRED]
+    # the enclosing tree + red cluster + deep (+ its own yellow cluster) + the cyan cluster twice — and twice again whatever
+    # BVHNode::new left alone in a slice of one (bvh.rs:44-45: evaluated on both sides)
+    assert len(bvh) == len(dfr) + 1 and len(dfr) >= 5 and sum(1 for it in items if it.flags & abi.ITEMFLAG_SAVE_T0) == 1
+    assert items[1].kind == abi.ITEM_BVH and items[1].flags & abi.ITEMFLAG_SAVE_T0 and not (items[1].flags & abi.ITEMFLAG_DEFERRED)
+    for it in dfr:
+        assert not (it.flags & abi.ITEMFLAG_MEDIUM)
+        g = (it.flags >> abi.RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15
+        assert 2 <= g <= it.xform_count  # the item's Traslate(Rotate(..)) in front of every chain
+        kinds = [a["xforms"][it.xform_first + k].kind for k in range(it.xform_count + 2)]
+        assert kinds[-2:] == [abi.XF_GATE_MIN, abi.XF_GATE_MAX] and all(k <= abi.XF_ROTATE_Z for k in kinds[:-2])
+    assert sum(1 for it in dfr if it.flags & abi.ITEMFLAG_FLIP) >= 1  # the flipped one (and the subtree nested in it)
+    assert sum(1 for it in items if (it.flags & abi.ITEMFLAG_DEFERRED) and (it.flags & abi.ITEMFLAG_MEDIUM)) >= 1
+
+
+def test_instanced_subtrees_mirror_equals_f64_oracle(host, orc64):
+    nx, ny = 48, 32
+    wh, wo = world_instanced_subtrees(host), world_instanced_subtrees(orc64)
+    ch, co = camera(host, nx, ny), camera(orc64, nx, ny)
+    for row in (8, 14, 18, 22):
+        ref = orc64.render(co, wo, nx, ny, 1, seed=42, rows=(row, row + 1))
+        for i in range(nx):
+            c = host.color_sample(ch, wh, nx, ny, i, ny - 1 - row, 0, seed=42)
+            assert np.array_equal(c, ref["mean"][row, i]), (row, i)
+    orc64.free_all()
+
+
 @pytest.mark.gpu
-def test_every_kernel_equals_the_fp32_oracle(host, orc32):
+@pytest.mark.parametrize("build", [world_media_in_bvh, world_instanced_subtrees], ids=["media", "instanced_subtrees"])
+def test_every_kernel_equals_the_fp32_oracle(host, orc32, build):
+    world_media_in_bvh = build  # noqa: F811 — the same comparison for both worlds
     nx, ny, ns = 120, 80, 24
     sc = host.lower(world_media_in_bvh(host))
     ref = orc32.render(camera(orc32, nx, ny), world_media_in_bvh(orc32), nx, ny, ns, seed=42, flags=ARITH_DEVICE | THROUGHPUT_FORM)
