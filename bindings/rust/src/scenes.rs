@@ -144,7 +144,7 @@ pub fn compositions(seed: u64) -> Rc<HittableDesc> {
 }
 
 /// ConstantMedium as a child of a BVHNode (twin of `media_in_bvh` in tools/dump_flat_scene.py; golden:
-/// tests/golden/flat_media_in_bvh.bin.gz): a BVH of primitives and media inside Traslate(Rotate(..)), a BVHNode over ONE
+/// tests/golden/flat_media_in_bvh.bin.gz): a BVH of primitives, media and an instanced subtree inside Traslate(Rotate(..)), a BVHNode over ONE
 /// object that is a BVH with a medium in it (evaluated on both sides), and a BVHNode over one medium (no primitives at all).
 pub fn media_in_bvh(seed: u64) -> Rc<HittableDesc> {
     let mut s = SceneStreams::new(seed);
@@ -157,12 +157,16 @@ pub fn media_in_bvh(seed: u64) -> Rc<HittableDesc> {
         traslate(constant_medium(cube([0.0, 0.0, 0.0], [1.2, 1.2, 1.2], glass.clone()), 2.5, solid_texture(0.2, 0.9, 0.2)), [1.8, -0.9, 0.8]),
         sphere([3.3, 0.1, -0.3], 0.8, grey.clone()),
     ];
+    // an instanced subtree (Traslate / Rotate around a BVHNode as a child of a BVHNode): a deferred BVH item with its gate records
+    let mut sub_list = vec![sphere([0.0, 0.0, 0.0], 0.4, grey.clone()), cube([0.5, -0.3, -0.3], [1.1, 0.3, 0.3], grey.clone())];
+    let sub = bvh_new(&mut sub_list, 0.0, 1.0, &mut s.backend);
+    objs.push(traslate(rotate(AXIS_Z, sub, 20.0), [4.5, 1.0, 0.5]));
     let mut inner_list = vec![
         sphere([-4.5, 1.2, 1.5], 0.5, grey.clone()),
         constant_medium(sphere([-4.2, 1.3, 1.4], 1.0, glass.clone()), 1.0, solid_texture(0.4, 0.9, 0.6)),
         cube([-5.6, 0.2, 0.8], [-5.0, 0.9, 1.6], grey),
     ];
-    // (construction order = the order of the scene stream's draws in the twin: inner first)
+    // (construction order = the order of the scene stream's draws in the twin: sub, inner, then the rest)
     let inner = bvh_new(&mut inner_list, 0.0, 1.0, &mut s.backend);
     let bvh = bvh_new(&mut objs, 0.0, 1.0, &mut s.backend);
     let mut one_bvh = vec![inner];

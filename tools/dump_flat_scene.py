@@ -109,7 +109,8 @@ def compositions(api, seed=1):
 
 def media_in_bvh(api, seed=1):
     """ConstantMedium as a child of a BVHNode (r04; twin of bindings/rust/src/scenes.rs `media_in_bvh`): a BVH of primitives
-    and media inside Traslate(Rotate(..)) — one medium around a plain boundary, one itself inside a Traslate —, a BVHNode
+    and media inside Traslate(Rotate(..)) — one medium around a plain boundary, one itself inside a Traslate, and an instanced
+    subtree (Traslate(Rotate(BVHNode))) —, a BVHNode
     over ONE object that is a BVH with a medium in it (evaluated on both sides: its medium twice), and a BVHNode over one
     medium (no primitives at all: no BVH item, the first deferred item remembers T0 itself)."""
     api.seed_scene_rng(seed)
@@ -120,6 +121,9 @@ def media_in_bvh(api, seed=1):
             api.Cube((0.3, -1.0, -0.8), (1.5, 0.4, 0.6), grey),
             api.Traslate(api.ConstantMedium(api.Cube((0.0, 0.0, 0.0), (1.2, 1.2, 1.2), glass), 2.5, api.SolidTexture(0.2, 0.9, 0.2)), (1.8, -0.9, 0.8)),
             api.Sphere((3.3, 0.1, -0.3), 0.8, grey)]
+    # an instanced subtree (Traslate / Rotate around a BVHNode as a child of a BVHNode): a deferred BVH item with its gate records
+    sub = api.BVHNode([api.Sphere((0.0, 0.0, 0.0), 0.4, grey), api.Cube((0.5, -0.3, -0.3), (1.1, 0.3, 0.3), grey)], 0.0, 1.0)
+    objs.append(api.Traslate(api.Rotate(api.AXIS_Z, sub, 20.0), (4.5, 1.0, 0.5)))
     inner = api.BVHNode([api.Sphere((-4.5, 1.2, 1.5), 0.5, grey),
                          api.ConstantMedium(api.Sphere((-4.2, 1.3, 1.4), 1.0, glass), 1.0, api.SolidTexture(0.4, 0.9, 0.6)),
                          api.Cube((-5.6, 0.2, 0.8), (-5.0, 0.9, 1.6), grey)], 0.0, 1.0)
