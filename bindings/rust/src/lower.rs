@@ -990,12 +990,10 @@ impl SceneBuilder {
             if d.chain_count > 15 || it.xform_count > 15 {
                 return Err(LowerError::Unsupported("a deferred child of a BVHNode inside more than 15 Traslate/Rotate wrappers".into()));
             }
-            if medium && is_bvh {
-                return Err(LowerError::Unsupported("a ConstantMedium whose boundary is a BVHNode cannot itself be a child of a BVHNode".into()));
-            }
             it.flags |= RTMI_ITEMFLAG_DEFERRED | ((d.chain_count as u32) << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) | (if d.save_t0 { RTMI_ITEMFLAG_SAVE_T0 } else { 0 });
-            if !medium {
-                // an instanced BVHNode: its gate travels in two records behind the chain (rtmi.h), before its primitives' own chains
+            if is_bvh {
+                // geometry = a BVHNode (an instanced subtree, or a medium's boundary): the gate travels in two records behind
+                // the chain (rtmi.h), before the primitives' own chains; its primitives keep their own gates
                 let (gmn, gmx) = put_box(&d.gate);
                 self.out.xforms.push(RtmiXform { kind: RTMI_XF_GATE_MIN, x: gmn[0], y: gmn[1], z: gmn[2] });
                 self.out.xforms.push(RtmiXform { kind: RTMI_XF_GATE_MAX, x: gmx[0], y: gmx[1], z: gmx[2] });
@@ -1108,7 +1106,7 @@ impl SceneBuilder {
         if let (Some(d), false) = (&deferred, medium) {
             it.count = d.rank; // leaves of the enclosing tree that precede it in traversal order (ties)
         }
-        if let (Some(d), true) = (&deferred, medium) {
+        if let (Some(d), true) = (&deferred, medium && it.kind == RTMI_ITEM_LIST) {
             // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
             let (gmn, gmx) = put_box(&d.gate);
             for q in it.first..it.first + it.count {

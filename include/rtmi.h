@@ -163,9 +163,10 @@ enum { RTMI_ITEM_LIST = 0, RTMI_ITEM_BVH = 1 };
  * order; a BVHNode over one element, bvh.rs:44-45, evaluates — and draws — twice: two items):
  *   RTMI_ITEMFLAG_SAVE_T0   on the BVH item (or, when the BVH holds nothing but media and there is no BVH item, on the
  *                           first deferred one): remember the closest hit so far as it stands BEFORE this item (T0);
- *   RTMI_ITEMFLAG_DEFERRED  a MEDIUM item of kind LIST: its boundary is queried only for rays whose gate passes
- *                           AABB::hit(t_min, T0) — the gate is prim_gate of the item's first primitive (the box of the
- *                           BVHNode the medium was a child of), the ray is the one the FIRST G transforms of the item hand
+ *   RTMI_ITEMFLAG_DEFERRED  a MEDIUM item: its boundary is queried only for rays whose gate passes
+ *                           AABB::hit(t_min, T0) — the gate is the box of the BVHNode the medium was a child of: prim_gate of
+ *                           the item's first primitive (kind LIST), the two records behind the chain as below (a boundary
+ *                           that is itself a BVHNode: kind BVH) —, the ray is the one the FIRST G transforms of the item hand
  *                           down (G in bits 12..15: the transforms of the enclosing BVH item, copied in front of the
  *                           medium's own) —, its interval is clamped to T0, and its hit is accepted when closer than the
  *                           closest hit so far (an exact tie with a primitive, of probability zero, goes to the primitive).

@@ -278,16 +278,16 @@ static int validate(const rtmi_scene_desc *d) {
             if (d->xforms[it.xform_first + k].kind > RTMI_XF_ROTATE_Z) return fail(RTMI_ERR_INVALID, "a gate record inside an item's transform chain");
         if (it.flags & RTMI_ITEMFLAG_DEFERRED) { // a medium or an instanced subtree that was a child of a BVHNode (rtmi.h)
             const int32_t G = (int32_t)((it.flags >> RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15u);
-            if (it.flags & RTMI_ITEMFLAG_MEDIUM) {
-                if (it.kind != RTMI_ITEM_LIST || it.count < 1 || !d->prim_gate)
-                    return fail(RTMI_ERR_INVALID, "a DEFERRED medium must be of kind LIST with at least one primitive, and prim_gate must be given");
-                if (G > (int32_t)((it.flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u))
-                    return fail(RTMI_ERR_INVALID, "a DEFERRED medium's enclosing transforms must be among those that wrap the medium");
+            if (it.kind == RTMI_ITEM_LIST) {
+                if (!(it.flags & RTMI_ITEMFLAG_MEDIUM) || it.count < 1 || !d->prim_gate)
+                    return fail(RTMI_ERR_INVALID, "a DEFERRED item of kind LIST must be a MEDIUM with at least one primitive, and prim_gate must be given");
             } else {
-                if (it.kind != RTMI_ITEM_BVH || G > it.xform_count || (uint32_t)(it.xform_first + it.xform_count) + 2u > d->n_xforms ||
+                if (G > it.xform_count || (uint32_t)(it.xform_first + it.xform_count) + 2u > d->n_xforms ||
                     d->xforms[it.xform_first + it.xform_count].kind != RTMI_XF_GATE_MIN || d->xforms[it.xform_first + it.xform_count + 1].kind != RTMI_XF_GATE_MAX)
-                    return fail(RTMI_ERR_INVALID, "a DEFERRED item without the MEDIUM flag must be of kind BVH with its two gate records behind its transform chain");
+                    return fail(RTMI_ERR_INVALID, "a DEFERRED item of kind BVH needs its two gate records behind its transform chain");
             }
+            if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && G > (int32_t)((it.flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u))
+                return fail(RTMI_ERR_INVALID, "a DEFERRED medium's enclosing transforms must be among those that wrap the medium");
         }
     }
     for (uint32_t i = 0; i < d->n_materials; i++) {

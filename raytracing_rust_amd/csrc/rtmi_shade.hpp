@@ -278,10 +278,10 @@ __device__ __forceinline__ bool deferred_gate(const DevScene &sc, const rtmi_ite
     RayF Rg = W;
     if (G > 0 && xform_ray(sc.xforms, I.xform_first, G, Rg.o, Rg.d)) ray_derive(Rg);
     float4 g0, g1;
-    if (I.flags & RTMI_ITEMFLAG_MEDIUM) { // a medium: the gate of its first boundary primitive
+    if (I.kind == RTMI_ITEM_LIST) { // a medium around primitives: the gate of its first boundary primitive
         const float4 *rec = sc.leaf_rec + (size_t)I.first * 5;
         g0 = rec[3]; g1 = rec[4];
-    } else { // an instanced BVHNode: the two records behind its chain ({kind, x, y, z})
+    } else { // geometry = a BVHNode (an instanced subtree, a medium's boundary): the two records behind its chain ({kind, x, y, z})
         const float4 *rec = reinterpret_cast<const float4 *>(sc.xforms + I.xform_first + I.xform_count);
         g0 = make_float4(rec[0].y, rec[0].z, rec[0].w, 0.0f); g1 = make_float4(rec[1].y, rec[1].z, rec[1].w, 0.0f);
     }

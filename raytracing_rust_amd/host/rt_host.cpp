@@ -1230,10 +1230,10 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
         const bool is_bvh = dynamic_cast<const BVHNode *>(h) != nullptr;
         if (!medium && !is_bvh) throw Panic("lower_item: a deferred item must be a ConstantMedium or an instanced BVHNode");
         if (deferred->chain_count > 15 || it.xform_count > 15) throw Unsupported("a deferred child of a BVHNode inside more than 15 Traslate/Rotate wrappers");
-        if (medium && is_bvh) throw Unsupported("a ConstantMedium whose boundary is a BVHNode cannot itself be a child of a BVHNode");
         it.flags |= RTMI_ITEMFLAG_DEFERRED | ((uint32_t)deferred->chain_count << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) |
                     (deferred->save_t0 ? RTMI_ITEMFLAG_SAVE_T0 : 0u);
-        if (!medium) { // an instanced BVHNode: its gate travels in two records behind the chain (rtmi.h), before its primitives' own chains
+        if (is_bvh) { // geometry = a BVHNode (an instanced subtree, or a medium's boundary): the gate travels in two records
+                      // behind the chain (rtmi.h), before the primitives' own chains; its primitives keep their own gates
             float gmn[3], gmx[3];
             put_box(gmn, gmx, deferred->gate);
             rtmi_xform g0{}, g1{};
@@ -1329,7 +1329,7 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
     }
     run_item_ = -1;
     if (deferred && !medium) it.count = deferred->rank; // leaves of the enclosing tree that precede it in traversal order (ties)
-    if (deferred && medium) { // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
+    if (deferred && medium && it.kind == RTMI_ITEM_LIST) { // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
         float gmn[3], gmx[3];
         put_box(gmn, gmx, deferred->gate);
         for (int32_t q = it.first; q < it.first + it.count; q++) {

@@ -124,6 +124,10 @@ def random_scene(api, seed, only=None, instanced=False):
                         else api.Cube(rng2.uniform(-2.0, 0, 3), rng2.uniform(0.4, 1.8, 3), api.Dielectric(1.5))
                     if rng2.random() < 0.4:
                         bq = _wrap(api, rng2, bq, allow_flip=False)
+                    elif rng2.random() < 0.3:  # a boundary that is itself a BVHNode (two overlapping shapes)
+                        c2 = rng2.uniform(-1.5, 1.5, 3)
+                        bq = api.BVHNode([api.Sphere(c2, float(rng2.uniform(0.5, 1.0)), api.Dielectric(1.5)),
+                                          api.Cube(c2 - rng2.uniform(0.2, 0.9, 3), c2 + rng2.uniform(0.2, 0.9, 3), api.Dielectric(1.5))], 0.0, 1.0)
                     md = api.ConstantMedium(bq, float(rng2.choice([0.05, 0.4, 1.5, 5.0])), api.SolidTexture(*rng2.uniform(0.1, 0.95, 3)))
                     if rng2.random() < 0.3:
                         md = api.Traslate(md, rng2.uniform(-1.0, 1.0, 3))

@@ -114,8 +114,16 @@ def test_unsupported_nesting_fails_loudly(host):
     # (a medium as a child of a BVHNode lowers since r04, as a DEFERRED item behind the BVH item: tests/test_media_in_bvh.py)
     b = host.lower(host.BVHNode([host.Traslate(inner, (1, 0, 0)), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0)).arrays()
     assert [bool(it.flags & abi.ITEMFLAG_DEFERRED) for it in b["items"]] == [False, True] and b["items"][0].flags & abi.ITEMFLAG_SAVE_T0
-    with pytest.raises(Unsupported):  # ... but not a medium whose boundary is itself a BVHNode
-        host.lower(host.BVHNode([host.ConstantMedium(sub, 0.3, tex), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0))
+    # ... also a medium whose boundary is itself a BVHNode: a DEFERRED MEDIUM item of kind BVH, its gate behind its (empty) chain
+    e = host.lower(host.BVHNode([host.ConstantMedium(sub, 0.3, tex), host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0)).arrays()
+    dm = [it for it in e["items"] if it.flags & abi.ITEMFLAG_DEFERRED]
+    assert len(dm) >= 1 and all(it.kind == abi.ITEM_BVH and it.flags & abi.ITEMFLAG_MEDIUM for it in dm)
+    assert [e["xforms"][dm[0].xform_first + dm[0].xform_count + k].kind for k in range(2)] == [abi.XF_GATE_MIN, abi.XF_GATE_MAX]
+    with pytest.raises(Unsupported):  # ... but not media as members of a list that is a BVH child
+        lst = host.HittableList()
+        lst.push(inner)
+        lst.push(host.Sphere((0, 3, 0), 1.0, mat))
+        host.lower(host.BVHNode([lst, host.Sphere((3, 0, 0), 1.0, mat)], 0.0, 1.0))
     with pytest.raises(Unsupported):
         host.lower(host.HittableList())  # empty world
 

@@ -70,6 +70,9 @@ def world_instanced_subtrees(api):
         api.Cube((0.8, -1.0, -0.6), (1.8, 0.2, 0.6), lam(0.3, 0.8, 0.3)),
         api.FlipNormals(api.Rotate(api.AXIS_X, api.Traslate(deep, (3.6, 0.2, 0.0)), 10.0)),
         api.BVHNode([api.Traslate(cluster((0.2, 0.9, 0.9)), (-2.8, 1.9, -1.2))], 0.0, 1.0),  # a one-element node over an instanced subtree: twice
+        # a medium whose boundary is itself a BVHNode (two overlapping shapes), as a child of the enclosing BVHNode
+        api.ConstantMedium(api.BVHNode([api.Sphere((3.2, 1.9, 1.0), 0.7, glass), api.Cube((3.0, 1.2, 0.4), (4.2, 2.0, 1.3), glass)], 0.0, 1.0), 1.2,
+                           api.SolidTexture(0.9, 0.6, 0.2)),
     ]
     w.push(api.Traslate(api.Rotate(api.AXIS_Y, api.BVHNode(objs, 0.0, 1.0), -15.0), (0.3, 0.2, 1.0)))
     return w
@@ -136,16 +139,16 @@ def test_instanced_subtrees_lower_as_deferred_bvh_items(host):
     dfr = [it for it in bvh if it.flags & abi.ITEMFLAG_DEFERRED]
     # the enclosing tree + red cluster + deep (+ its own yellow cluster) + the cyan cluster twice — and twice again whatever
     # BVHNode::new left alone in a slice of one (bvh.rs:44-45: evaluated on both sides)
-    assert len(bvh) == len(dfr) + 1 and len(dfr) >= 5 and sum(1 for it in items if it.flags & abi.ITEMFLAG_SAVE_T0) == 1
+    assert len(bvh) == len(dfr) + 1 and len(dfr) >= 6 and sum(1 for it in items if it.flags & abi.ITEMFLAG_SAVE_T0) == 1
     assert items[1].kind == abi.ITEM_BVH and items[1].flags & abi.ITEMFLAG_SAVE_T0 and not (items[1].flags & abi.ITEMFLAG_DEFERRED)
+    assert sum(1 for it in dfr if it.flags & abi.ITEMFLAG_MEDIUM) >= 1  # the medium around a BVHNode boundary
     for it in dfr:
-        assert not (it.flags & abi.ITEMFLAG_MEDIUM)
         g = (it.flags >> abi.RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15
         assert 2 <= g <= it.xform_count  # the item's Traslate(Rotate(..)) in front of every chain
         kinds = [a["xforms"][it.xform_first + k].kind for k in range(it.xform_count + 2)]
         assert kinds[-2:] == [abi.XF_GATE_MIN, abi.XF_GATE_MAX] and all(k <= abi.XF_ROTATE_Z for k in kinds[:-2])
     assert sum(1 for it in dfr if it.flags & abi.ITEMFLAG_FLIP) >= 1  # the flipped one (and the subtree nested in it)
-    assert sum(1 for it in items if (it.flags & abi.ITEMFLAG_DEFERRED) and (it.flags & abi.ITEMFLAG_MEDIUM)) >= 1
+    assert sum(1 for it in items if (it.flags & abi.ITEMFLAG_DEFERRED) and (it.flags & abi.ITEMFLAG_MEDIUM) and it.kind == abi.ITEM_LIST) >= 1
 
 
 def test_instanced_subtrees_mirror_equals_f64_oracle(host, orc64):
