@@ -937,7 +937,8 @@ impl SceneBuilder {
     fn lower_item_deferred(&mut self, top: &Rc<HittableDesc>, deferred: Option<DeferredMedium>) -> Result<(), LowerError> {
         let mut it = zero_item();
         it.xform_first = self.out.xforms.len() as i32;
-        let (mut flip, mut medium) = (false, false);
+        let (mut flip, mut medium, mut nested) = (false, false, false);
+        let mut inner_neg_inv_density = 0.0f32;
         let mut medium_outer = 0u32;
         let mut h = top;
         if let Some(d) = &deferred {
@@ -957,7 +958,17 @@ impl SceneBuilder {
                 }
                 HittableDesc::ConstantMedium { boundary, density, phase } => {
                     if medium {
-                        return Err(LowerError::Unsupported("nested ConstantMedium is not lowered".into()));
+                        // a medium as the boundary of a medium (medium.rs:11-15 is generic): one level, no wrappers in between
+                        if nested {
+                            return Err(LowerError::Unsupported("ConstantMedium nested more than once is not lowered".into()));
+                        }
+                        if it.xform_count as u32 != medium_outer {
+                            return Err(LowerError::Unsupported("Traslate / Rotate between a ConstantMedium and the ConstantMedium that is its boundary is not lowered".into()));
+                        }
+                        nested = true;
+                        inner_neg_inv_density = -(1.0f32 / (*density as f32)); // (its phase function never shows: the hit record is the outer medium's)
+                        h = boundary;
+                        continue;
                     }
                     if it.xform_count > 15 {
                         return Err(LowerError::Unsupported("ConstantMedium inside more than 15 Traslate/Rotate wrappers".into()));
@@ -981,7 +992,15 @@ impl SceneBuilder {
                 _ => break,
             }
         }
-        it.flags = (if flip { RTMI_ITEMFLAG_FLIP } else { 0 }) | (if medium { RTMI_ITEMFLAG_MEDIUM } else { 0 }) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT);
+        it.flags = (if flip { RTMI_ITEMFLAG_FLIP } else { 0 })
+            | (if medium { RTMI_ITEMFLAG_MEDIUM } else { 0 })
+            | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT)
+            | (if nested { RTMI_ITEMFLAG_NESTED_MEDIUM } else { 0 });
+        // the inner medium's record: behind the chain (behind the gate records of a DEFERRED BVH item)
+        let inner_record = RtmiXform { kind: RTMI_XF_INNER_MEDIUM, x: inner_neg_inv_density, y: 0.0, z: 0.0 };
+        if nested && deferred.is_none() {
+            self.out.xforms.push(inner_record);
+        }
         if let Some(d) = &deferred {
             let is_bvh = matches!(&**h, HittableDesc::Bvh { .. });
             if !medium && !is_bvh {
@@ -997,6 +1016,9 @@ impl SceneBuilder {
                 let (gmn, gmx) = put_box(&d.gate);
                 self.out.xforms.push(RtmiXform { kind: RTMI_XF_GATE_MIN, x: gmn[0], y: gmn[1], z: gmn[2] });
                 self.out.xforms.push(RtmiXform { kind: RTMI_XF_GATE_MAX, x: gmx[0], y: gmx[1], z: gmx[2] });
+            }
+            if nested {
+                self.out.xforms.push(inner_record);
             }
         }
         match &**h {

@@ -54,6 +54,8 @@ pub const RTMI_XF_ROTATE_Z: i32 = 3;
 /// not transforms: the two records behind the chain of a DEFERRED BVH item hold its gate box
 pub const RTMI_XF_GATE_MIN: i32 = 4;
 pub const RTMI_XF_GATE_MAX: i32 = 5;
+/// not a transform: x = -(1/density) of the inner medium of a nested pair, behind the chain (and the gate records)
+pub const RTMI_XF_INNER_MEDIUM: i32 = 6;
 pub const RTMI_ITEM_LIST: i32 = 0;
 pub const RTMI_ITEM_BVH: i32 = 1;
 pub const RTMI_ITEMFLAG_FLIP: u32 = 1;
@@ -64,6 +66,8 @@ pub const RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT: u32 = 8;
 /// (or on the first deferred one when the BVH holds nothing but media) remembers the closest hit before it
 pub const RTMI_ITEMFLAG_SAVE_T0: u32 = 4;
 pub const RTMI_ITEMFLAG_DEFERRED: u32 = 8;
+/// a ConstantMedium whose boundary is a ConstantMedium: the inner density travels in an RTMI_XF_INNER_MEDIUM record
+pub const RTMI_ITEMFLAG_NESTED_MEDIUM: u32 = 16;
 /// DEFERRED items: bits 12..15 = number of leading transforms that belong to the enclosing BVH item
 pub const RTMI_ITEMFLAG_GATE_OUTER_SHIFT: u32 = 12;
 pub const RTMI_NO_CHILD: i32 = 0x7fff_ffff;

@@ -135,7 +135,10 @@ typedef struct {
 /* ---- instance transforms: Traslate (src/traslate.rs), Rotate (src/rotate.rs) ---- */
 enum { RTMI_XF_TRANSLATE = 0, RTMI_XF_ROTATE_X = 1, RTMI_XF_ROTATE_Y = 2, RTMI_XF_ROTATE_Z = 3,
        /* not transforms: the two records BEHIND the chain of a DEFERRED BVH item hold its gate box (x, y, z = min / max) */
-       RTMI_XF_GATE_MIN = 4, RTMI_XF_GATE_MAX = 5 };
+       RTMI_XF_GATE_MIN = 4, RTMI_XF_GATE_MAX = 5,
+       /* not a transform either: x = -(1/density) of the INNER medium of a nested pair (RTMI_ITEMFLAG_NESTED_MEDIUM), the
+        * record behind the chain (and behind the two gate records of a DEFERRED BVH item) */
+       RTMI_XF_INNER_MEDIUM = 6 };
 typedef struct {
     int32_t kind;
     float x, y, z; /* TRANSLATE: offset | ROTATE_*: x = sin(theta), y = cos(theta) */
@@ -178,6 +181,13 @@ enum { RTMI_ITEM_LIST = 0, RTMI_ITEM_BVH = 1 };
  * later child wins; ties between deferred items of one group go to the later item). */
 #define RTMI_ITEMFLAG_SAVE_T0 4u
 #define RTMI_ITEMFLAG_DEFERRED 8u
+/* A ConstantMedium whose boundary is a ConstantMedium (medium.rs:11-15 is generic over any Hittable): the outer medium's
+ * two boundary queries (medium.rs:30-31) are two evaluations of the inner medium — each of which queries the geometry
+ * twice and draws its own random number when its interval is not empty — and their two random distances bound the
+ * interval the outer medium then samples (third draw).  MEDIUM items with this flag carry the inner medium's -(1/density)
+ * in an RTMI_XF_INNER_MEDIUM record behind their chain; material and density of the item are the OUTER medium's (the hit
+ * record is its own, medium.rs:47-54).  One level, no wrappers between the two media. */
+#define RTMI_ITEMFLAG_NESTED_MEDIUM 16u
 #define RTMI_ITEMFLAG_GATE_OUTER_SHIFT 12
 typedef struct {
     int32_t kind;

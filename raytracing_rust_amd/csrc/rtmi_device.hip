@@ -189,9 +189,11 @@ static int validate(const rtmi_scene_desc *d) {
             return fail(RTMI_ERR_INVALID, "primitive material out of range");
         const uint32_t xfc = (m.flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX, xff = m.flags >> RTMI_PRIMFLAG_XF_FIRST_SHIFT;
         if (xfc != 0u && ((uint64_t)xff + xfc > d->n_xforms)) return fail(RTMI_ERR_INVALID, "primitive transform range out of bounds");
+        for (uint32_t k = 0; k < xfc; k++) // (gate and inner-medium records are no transforms: never inside a chain)
+            if (d->xforms[xff + k].kind > RTMI_XF_ROTATE_Z) return fail(RTMI_ERR_INVALID, "a gate or inner-medium record inside a primitive's transform chain");
     }
     for (uint32_t i = 0; i < d->n_xforms; i++)
-        if (d->xforms[i].kind < RTMI_XF_TRANSLATE || d->xforms[i].kind > RTMI_XF_GATE_MAX) return fail(RTMI_ERR_INVALID, "bad transform kind");
+        if (d->xforms[i].kind < RTMI_XF_TRANSLATE || d->xforms[i].kind > RTMI_XF_INNER_MEDIUM) return fail(RTMI_ERR_INVALID, "bad transform kind");
     for (uint32_t i = 0; i < d->n_nodes; i++) {
         const int32_t ch[2] = {d->nodes[i].left, d->nodes[i].right};
         for (int c = 0; c < 2; c++) {
@@ -276,6 +278,11 @@ static int validate(const rtmi_scene_desc *d) {
             return fail(RTMI_ERR_INVALID, "more outer medium transforms than the item has transforms");
         for (int32_t k = 0; k < it.xform_count; k++) // (the gate records are no transforms: never inside a chain)
             if (d->xforms[it.xform_first + k].kind > RTMI_XF_ROTATE_Z) return fail(RTMI_ERR_INVALID, "a gate record inside an item's transform chain");
+        if (it.flags & RTMI_ITEMFLAG_NESTED_MEDIUM) { // a medium whose boundary is a medium: the inner density behind the chain (rtmi.h)
+            const uint32_t at = (uint32_t)(it.xform_first + it.xform_count) + (((it.flags & RTMI_ITEMFLAG_DEFERRED) && it.kind == RTMI_ITEM_BVH) ? 2u : 0u);
+            if (!(it.flags & RTMI_ITEMFLAG_MEDIUM) || at >= d->n_xforms || d->xforms[at].kind != RTMI_XF_INNER_MEDIUM)
+                return fail(RTMI_ERR_INVALID, "a NESTED_MEDIUM item must be a MEDIUM with its RTMI_XF_INNER_MEDIUM record behind its transform chain");
+        }
         if (it.flags & RTMI_ITEMFLAG_DEFERRED) { // a medium or an instanced subtree that was a child of a BVHNode (rtmi.h)
             const int32_t G = (int32_t)((it.flags >> RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15u);
             if (it.kind == RTMI_ITEM_LIST) {
@@ -354,8 +361,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         std::vector<rtmi_item> items(d->items, d->items + d->n_items);
         for (rtmi_item &it : items) {
             it.flags &= (RTMI_ITEMFLAG_FLIP | RTMI_ITEMFLAG_MEDIUM | (15u << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) | RTMI_ITEMFLAG_SAVE_T0 |
-                         RTMI_ITEMFLAG_DEFERRED | (15u << RTMI_ITEMFLAG_GATE_OUTER_SHIFT));
-            if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && !(it.flags & RTMI_ITEMFLAG_DEFERRED) && it.kind == RTMI_ITEM_LIST && it.count == 1 &&
+                         RTMI_ITEMFLAG_DEFERRED | (15u << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) | RTMI_ITEMFLAG_NESTED_MEDIUM);
+            if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && !(it.flags & (RTMI_ITEMFLAG_DEFERRED | RTMI_ITEMFLAG_NESTED_MEDIUM)) && it.kind == RTMI_ITEM_LIST && it.count == 1 &&
                 d->prim_meta[it.first].type == RTMI_PRIM_SPHERE &&
                 ((d->prim_meta[it.first].flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) == 0u) {
                 // (a sphere with a transform chain of its own — ConstantMedium(HittableList[Traslate(Sphere)]) — takes the
@@ -453,10 +460,10 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         if ((d->prim_meta[i].flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) s->dev.has_prim_xf = 1u;
     s->dev.has_medium_outer = 0u;
     for (uint32_t i = 0; i < d->n_items; i++)
-        if (((d->items[i].flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) || (d->items[i].flags & (RTMI_ITEMFLAG_SAVE_T0 | RTMI_ITEMFLAG_DEFERRED)))
+        if (((d->items[i].flags >> RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15u) || (d->items[i].flags & (RTMI_ITEMFLAG_SAVE_T0 | RTMI_ITEMFLAG_DEFERRED | RTMI_ITEMFLAG_NESTED_MEDIUM)))
             s->dev.has_medium_outer = 1u; // (deferred media ride in the same instantiations as media inside transforms)
     for (uint32_t i = 0; i < d->n_items; i++)
-        if (d->items[i].flags & RTMI_ITEMFLAG_DEFERRED) s->has_deferred = true;
+        if (d->items[i].flags & (RTMI_ITEMFLAG_DEFERRED | RTMI_ITEMFLAG_NESTED_MEDIUM)) s->has_deferred = true;
     if (hipMalloc(reinterpret_cast<void **>(&s->status), RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess ||
         hipMemset(s->status, 0, RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess) {
         rtmi_scene_destroy(s);

@@ -108,7 +108,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                         if (!dfr || deferred_gate(sc, I, W, P.t_min, t0_saved)) {
                         if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, stack, t1, pf, prof, slot)) {
                             if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, stack, t2, pf, prof, slot)) {
-                                if (medium_sample(t1, t2, P.t_min, qmax, medium_dir_norm(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
+                                const float dn = medium_dir_norm(sc, I.flags, I.xform_first, W);
+                                if ((I.flags & RTMI_ITEMFLAG_NESTED_MEDIUM) && !nested_medium_interval(sc, I, dn, g, k0, k1, t1, t2)) {
+                                    // the inner medium returned no hit to one of the outer medium's two queries
+                                } else
+                                if (medium_sample(t1, t2, P.t_min, qmax, dn, I.neg_inv_density, g, k0, k1, tm)) {
                                     if (!dfr || tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }
                                 }
                             }
@@ -275,6 +279,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         if (dfr) reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
                         h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, reach, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
                         h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, reach && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
+                        if (INST && (I.flags & RTMI_ITEMFLAG_NESTED_MEDIUM)) { // wave-uniform: the boundary is itself a medium (rtmi.h)
+                            if (reach && h1 && h2) h1 = nested_medium_interval(sc, I, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), g, k0, k1, t1, t2);
+                        }
                         if (dfr) { // its interval ends at the t_max the BVH was entered with; its hit must beat what the tree found
                             if (reach && h1 && h2 && medium_sample(t1, t2, t_min, t0_saved, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
                                 if (tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }

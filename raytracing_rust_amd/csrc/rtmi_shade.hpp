@@ -315,6 +315,24 @@ __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, f
     return false;
 }
 
+// A ConstantMedium whose boundary is a ConstantMedium (RTMI_ITEMFLAG_NESTED_MEDIUM, rtmi.h).  The outer medium's two boundary
+// queries (medium.rs:30-31) are two calls of the inner medium's hit(): (ray, -MAX, MAX) and (ray, hit1.t + 0.0001, MAX).
+// Either call queries the geometry with the same two intervals — (t1, t2) on entry, found once by the caller — clamps, and
+// draws one random number when its interval is not empty; the second call happens only when the first returned a hit.  On
+// return (t1, t2) are the two random distances: the interval the outer medium then clamps and samples (its own draw).
+// The inner medium sees the same ray as the outer one (no wrappers in between: refused by the lowerings), hence `dn`.
+template <typename RngT>
+__device__ __forceinline__ bool nested_medium_interval(const DevScene &sc, const rtmi_item &I, float dn, RngT &g, uint32_t k0, uint32_t k1,
+                                                       float &t1, float &t2) {
+    const int at = I.xform_first + I.xform_count + (((I.flags & RTMI_ITEMFLAG_DEFERRED) && I.kind == RTMI_ITEM_BVH) ? 2 : 0);
+    const float inner_nid = sc.xforms[at].x;
+    float ta, tb;
+    if (!medium_sample(t1, t2, -RTMI_FLT_MAX, RTMI_FLT_MAX, dn, inner_nid, g, k0, k1, ta)) return false;
+    if (!medium_sample(t1, t2, ta + 0.0001f, RTMI_FLT_MAX, dn, inner_nid, g, k0, k1, tb)) return false;
+    t1 = ta; t2 = tb;
+    return true;
+}
+
 // HitRecord of the closest hit (hittable.rs:9-16), built once, then
 // color(): emitted + attenuation * color(scattered) — color.rs:8-15, in throughput form.
 // ALL 64 lanes call this together (the texture lookup is a wavefront operation, tex_value_wave); lanes with

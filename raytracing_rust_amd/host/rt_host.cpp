@@ -1189,7 +1189,8 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
     rtmi_item it{};
     it.alt_first = -1;
     it.xform_first = (int32_t)out.xforms.size();
-    bool flip = false, medium = false;
+    bool flip = false, medium = false, nested = false;
+    float inner_neg_inv_density = 0.0f;
     uint32_t medium_outer = 0;
     const Hittable *h = &top;
     if (deferred) { // a child of a BVHNode lowered as an item: it sits inside the transforms of that BVH item — a copy of them first —
@@ -1200,7 +1201,14 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
     for (;;) { // peel wrappers, outermost first
         if (auto f = dynamic_cast<const FlipNormals *>(h)) { flip = !flip; h = f->inner().get(); continue; }
         if (auto m = dynamic_cast<const ConstantMedium *>(h)) {
-            if (medium) throw Unsupported("nested ConstantMedium is not lowered");
+            if (medium) { // a medium as the boundary of a medium (medium.rs:11-15 is generic): one level, no wrappers in between
+                if (nested) throw Unsupported("ConstantMedium nested more than once is not lowered");
+                if ((uint32_t)it.xform_count != medium_outer) throw Unsupported("Traslate / Rotate between a ConstantMedium and the ConstantMedium that is its boundary is not lowered");
+                nested = true;
+                inner_neg_inv_density = -(1.0f / (float)m->density_); // (its phase function never shows: the hit record is the outer medium's)
+                h = m->boundary_.get();
+                continue;
+            }
             if (it.xform_count > 15) throw Unsupported("ConstantMedium inside more than 15 Traslate/Rotate wrappers");
             medium_outer = (uint32_t)it.xform_count; // the wrappers peeled so far hold the medium itself, not its boundary
             medium = true;
@@ -1225,7 +1233,15 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
         }
         break;
     }
-    it.flags = (flip ? RTMI_ITEMFLAG_FLIP : 0u) | (medium ? RTMI_ITEMFLAG_MEDIUM : 0u) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT);
+    it.flags = (flip ? RTMI_ITEMFLAG_FLIP : 0u) | (medium ? RTMI_ITEMFLAG_MEDIUM : 0u) | (medium_outer << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) |
+               (nested ? RTMI_ITEMFLAG_NESTED_MEDIUM : 0u);
+    const auto push_inner_medium = [&]() { // the record behind the chain (behind the gate records of a DEFERRED BVH item)
+        if (!nested) return;
+        rtmi_xform r{};
+        r.kind = RTMI_XF_INNER_MEDIUM; r.x = inner_neg_inv_density;
+        out.xforms.push_back(r);
+    };
+    if (!deferred) push_inner_medium();
     if (deferred) {
         const bool is_bvh = dynamic_cast<const BVHNode *>(h) != nullptr;
         if (!medium && !is_bvh) throw Panic("lower_item: a deferred item must be a ConstantMedium or an instanced BVHNode");
@@ -1241,6 +1257,7 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
             g1.kind = RTMI_XF_GATE_MAX; g1.x = gmx[0]; g1.y = gmx[1]; g1.z = gmx[2];
             out.xforms.push_back(g0); out.xforms.push_back(g1);
         }
+        push_inner_medium();
     }
     if (auto bvh = dynamic_cast<const BVHNode *>(h)) {
         if (!has_prims(bvh)) { // nothing but media below: no BVH item at all, only the deferred ones

@@ -128,6 +128,8 @@ def random_scene(api, seed, only=None, instanced=False):
                         c2 = rng2.uniform(-1.5, 1.5, 3)
                         bq = api.BVHNode([api.Sphere(c2, float(rng2.uniform(0.5, 1.0)), api.Dielectric(1.5)),
                                           api.Cube(c2 - rng2.uniform(0.2, 0.9, 3), c2 + rng2.uniform(0.2, 0.9, 3), api.Dielectric(1.5))], 0.0, 1.0)
+                    if rng2.random() < 0.25:  # a medium as the boundary of the medium (medium.rs:11-15 is generic): three draws
+                        bq = api.ConstantMedium(bq, float(rng2.choice([0.3, 1.0, 3.0])), api.SolidTexture(0.5, 0.5, 0.5))
                     md = api.ConstantMedium(bq, float(rng2.choice([0.05, 0.4, 1.5, 5.0])), api.SolidTexture(*rng2.uniform(0.1, 0.95, 3)))
                     if rng2.random() < 0.3:
                         md = api.Traslate(md, rng2.uniform(-1.0, 1.0, 3))
@@ -177,6 +179,8 @@ def random_scene(api, seed, only=None, instanced=False):
                 q = api.Sphere(rng2.uniform(-2, 2, 3), float(rng2.uniform(0.8, 2.0)), api.Dielectric(1.5))
                 lst.push(_wrap(api, rng2, api.Traslate(q, rng2.uniform(-1.0, 1.0, 3)), allow_flip=False))
                 b = lst
+            if instanced and rng2.random() < 0.25:  # nested media (tests/test_media_in_bvh.py, world_nested_media)
+                b = api.ConstantMedium(b, float(rng2.choice([0.2, 1.0, 4.0])), api.SolidTexture(0.5, 0.5, 0.5))
             med = api.ConstantMedium(b, float(rng.choice([0.0, 0.01, 0.2, 1.0, 5.0])), _texture(api, rng))
             if instanced and rng2.random() < 0.5:
                 med = _wrap(api, rng2, med)  # Traslate / Rotate / FlipNormals AROUND the medium (traslate.rs:6-9 is generic)

@@ -100,8 +100,14 @@ def test_unsupported_nesting_fails_loudly(host):
     inner = host.ConstantMedium(host.Sphere((0, 0, 0), 1.0, mat), 0.1, tex)
     a = host.lower(host.Rotate(host.AXIS_Y, host.Traslate(inner, (1, 0, 0)), 20.0)).arrays()  # a medium INSIDE two transforms lowers since r03
     assert (a["items"][0].flags >> abi.RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) & 15 == 2 and a["items"][0].xform_count == 2
+    # (a medium whose boundary is a medium lowers since r04 — one level, nothing in between: tests/test_media_in_bvh.py)
+    n2 = host.lower(host.ConstantMedium(inner, 0.2, tex)).arrays()
+    assert n2["items"][0].flags & abi.ITEMFLAG_NESTED_MEDIUM and n2["xforms"][0].kind == abi.XF_INNER_MEDIUM and n2["xforms"][0].x == np.float32(-10.0)
+    assert n2["items"][0].neg_inv_density == np.float32(-5.0)
     with pytest.raises(Unsupported):
-        host.lower(host.ConstantMedium(inner, 0.2, tex))  # nested media
+        host.lower(host.ConstantMedium(host.ConstantMedium(inner, 0.2, tex), 0.3, tex))  # two levels
+    with pytest.raises(Unsupported):
+        host.lower(host.ConstantMedium(host.Traslate(inner, (1, 0, 0)), 0.2, tex))  # a wrapper between the two
     # (an instanced PRIMITIVE as a BVH leaf lowers since r03: tests/test_random_scenes.py)
     sub = host.BVHNode([host.Sphere((0, 0, 0), 1.0, mat), host.Sphere((0, 2, 0), 1.0, mat)], 0.0, 1.0)
     # (an instanced BVHNode as a child of a BVHNode lowers since r04, as a DEFERRED BVH item with its gate records behind its chain)

@@ -78,6 +78,71 @@ def world_instanced_subtrees(api):
     return w
 
 
+def world_nested_media(api):
+    """A ConstantMedium whose boundary is a ConstantMedium (medium.rs:11-15 is generic over any Hittable): the inner one
+    answers either boundary query of the outer one with a random distance of its own — three draws per reached pair.  In the
+    world list, inside transforms, around several primitives, around a BVHNode, and as children of a BVHNode."""
+    api.seed_scene_rng(11)
+    lam = lambda r, g, b: api.Lambertian(api.SolidTexture(r, g, b))  # noqa: E731
+    glass = api.Dielectric(1.5)
+    fog = lambda boundary, d_in, d_out, r, g, b: api.ConstantMedium(api.ConstantMedium(boundary, d_in, api.SolidTexture(0.1, 0.1, 0.1)),  # noqa: E731
+                                                                     d_out, api.SolidTexture(r, g, b))
+    w = api.HittableList()
+    w.push(api.Rect(api.PLANE_ZX, -9.0, -9.0, 9.0, 9.0, -1.0, lam(0.6, 0.6, 0.6)))
+    w.push(api.Sphere((0.0, 10.0, 2.0), 3.0, api.DiffuseLight(api.SolidTexture(5.0, 5.0, 5.0))))
+    w.push(fog(api.Sphere((-3.5, 0.3, 0.0), 1.2, glass), 0.8, 1.5, 0.9, 0.3, 0.2))                        # one sphere
+    w.push(api.Traslate(api.Rotate(api.AXIS_Y, fog(api.Cube((-0.7, -0.7, -0.7), (0.7, 0.7, 0.7), glass), 1.5, 0.6, 0.2, 0.9, 0.3), 30.0),
+                        (-0.8, 0.0, 0.5)))                                                                # both inside transforms
+    two = api.HittableList()
+    two.push(api.Sphere((1.6, 0.0, 0.0), 0.8, glass))
+    two.push(api.Traslate(api.Sphere((0.0, 0.0, 0.0), 0.6, glass), (2.4, 0.5, 0.3)))
+    w.push(api.FlipNormals(fog(two, 0.5, 2.0, 0.2, 0.4, 0.9)))                                             # a list boundary
+    cluster = api.BVHNode([api.Sphere((4.0 + 0.5 * k, 0.2 * k, -0.5), 0.45, glass) for k in range(4)], 0.0, 1.0)
+    w.push(fog(cluster, 0.9, 1.1, 0.9, 0.9, 0.2))                                                          # a BVHNode boundary
+    objs = [api.Sphere((-3.0, 2.6, -1.0), 0.6, lam(0.8, 0.3, 0.3)),
+            fog(api.Sphere((-1.2, 2.6, -1.0), 0.9, glass), 0.7, 1.8, 0.3, 0.9, 0.9),                       # children of a BVHNode
+            api.Cube((0.2, 2.0, -1.6), (1.2, 3.0, -0.6), lam(0.3, 0.8, 0.3)),
+            api.Traslate(fog(api.BVHNode([api.Sphere((0.0, 0.0, 0.0), 0.5, glass), api.Sphere((0.7, 0.2, 0.0), 0.5, glass)], 0.0, 1.0),
+                             1.2, 0.9, 0.9, 0.5, 0.9), (2.4, 2.6, -1.0))]
+    w.push(api.Traslate(api.BVHNode(objs, 0.0, 1.0), (0.0, 0.2, 0.0)))
+    return w
+
+
+def test_nested_media_lower_with_the_inner_density_behind_the_chain(host):
+    a = host.lower(world_nested_media(host)).arrays()
+    nested = [it for it in a["items"] if it.flags & abi.ITEMFLAG_NESTED_MEDIUM]
+    assert len(nested) >= 6 and all(it.flags & abi.ITEMFLAG_MEDIUM for it in nested)
+    seen = set()
+    for it in nested:
+        at = it.xform_first + it.xform_count + (2 if (it.flags & abi.ITEMFLAG_DEFERRED) and it.kind == abi.ITEM_BVH else 0)
+        rec = a["xforms"][at]
+        assert rec.kind == abi.XF_INNER_MEDIUM and rec.x < 0.0
+        seen.add((bool(it.flags & abi.ITEMFLAG_DEFERRED), it.kind))
+        assert np.float32(rec.x) != np.float32(it.neg_inv_density)  # the item's own density is the OUTER medium's
+    assert seen == {(False, abi.ITEM_LIST), (False, abi.ITEM_BVH), (True, abi.ITEM_LIST), (True, abi.ITEM_BVH)}
+    # refused: wrappers between the two media, and a third level
+    glass = host.Dielectric(1.5)
+    tex = host.SolidTexture(0.5, 0.5, 0.5)
+    for bad in (host.ConstantMedium(host.Traslate(host.ConstantMedium(host.Sphere((0.0, 0.0, 0.0), 1.0, glass), 1.0, tex), (1.0, 0.0, 0.0)), 1.0, tex),
+                host.ConstantMedium(host.ConstantMedium(host.ConstantMedium(host.Sphere((0.0, 0.0, 0.0), 1.0, glass), 1.0, tex), 1.0, tex), 1.0, tex)):
+        w = host.HittableList()
+        w.push(bad)
+        with pytest.raises(Exception, match="not lowered"):
+            host.lower(w)
+
+
+def test_nested_media_mirror_equals_f64_oracle(host, orc64):
+    nx, ny = 48, 32
+    wh, wo = world_nested_media(host), world_nested_media(orc64)
+    ch, co = camera(host, nx, ny), camera(orc64, nx, ny)
+    for row in (8, 12, 16, 20, 24):
+        ref = orc64.render(co, wo, nx, ny, 1, seed=42, rows=(row, row + 1))
+        for i in range(nx):
+            c = host.color_sample(ch, wh, nx, ny, i, ny - 1 - row, 0, seed=42)
+            assert np.array_equal(c, ref["mean"][row, i]), (row, i)
+    orc64.free_all()
+
+
 def camera(api, nx, ny):
     return api.Camera((1.0, 3.0, 9.0), (0.0, 0.6, 0.5), (0.0, 1.0, 0.0), 42.0, nx / ny, 0.05, 9.0, 0.0, 1.0)
 
@@ -164,7 +229,7 @@ def test_instanced_subtrees_mirror_equals_f64_oracle(host, orc64):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("build", [world_media_in_bvh, world_instanced_subtrees], ids=["media", "instanced_subtrees"])
+@pytest.mark.parametrize("build", [world_media_in_bvh, world_instanced_subtrees, world_nested_media], ids=["media", "instanced_subtrees", "nested_media"])
 def test_every_kernel_equals_the_fp32_oracle(host, orc32, build):
     world_media_in_bvh = build  # noqa: F811 — the same comparison for both worlds
     nx, ny, ns = 120, 80, 24
