@@ -120,8 +120,36 @@ fn is_instanced_bvh_child(h: &Rc<HittableDesc>) -> bool {
     let core = strip_wrappers(h, &mut dummy, Some(&mut chain));
     matches!(&**core, HittableDesc::Bvh { .. }) && !chain.is_empty()
 }
+/// A HittableList with media among its members (nested lists and FlipNormals looked through) as a child of a BVHNode: the
+/// whole list leaves the tree — a group of DEFERRED member items and a terminator (rt_host.cpp list_holds_media; rtmi.h LISTSCAN)
+fn list_holds_media(list: &[Rc<HittableDesc>]) -> bool {
+    list.iter().any(|m| {
+        let mut d = false;
+        let s = strip_flips(m, &mut d);
+        match &**s {
+            HittableDesc::List { list: sub } => list_holds_media(sub),
+            _ => is_medium_child(s),
+        }
+    })
+}
+fn is_media_list_child(h: &Rc<HittableDesc>) -> bool {
+    let mut d = false;
+    matches!(&**strip_flips(h, &mut d), HittableDesc::List { list } if list_holds_media(list))
+}
+/// the members of a list in scan order, nested lists flattened, FlipNormals carried along (rt_host.cpp flatten_list_leaf)
+fn flatten_list(list: &[Rc<HittableDesc>], flip: bool, out: &mut Vec<(Rc<HittableDesc>, bool)>) {
+    for m in list {
+        let mut f = flip;
+        let h = strip_flips(m, &mut f);
+        if let HittableDesc::List { list: sub } = &**h {
+            flatten_list(sub, f, out);
+        } else {
+            out.push((h.clone(), f));
+        }
+    }
+}
 fn is_deferred_child(h: &Rc<HittableDesc>) -> bool {
-    is_medium_child(h) || is_instanced_bvh_child(h)
+    is_medium_child(h) || is_instanced_bvh_child(h) || is_media_list_child(h)
 }
 /// rt_host.cpp has_prims
 fn has_prims(h: &Rc<HittableDesc>) -> bool {
@@ -149,6 +177,8 @@ struct DeferredMedium {
     save_t0: bool,
     rank: i32,
     flip: bool,
+    /// LISTSCAN flags of a member of a list scan (0: not one)
+    scan: u32,
 }
 
 fn contains_moving(h: &Rc<HittableDesc>) -> bool {
@@ -596,23 +626,12 @@ impl SceneBuilder {
     /// below a balanced subtree of nodes whose boxes pass every ray.  Nested lists are flattened.
     fn lower_list_leaf(&mut self, list: &[Rc<HittableDesc>], holder: &Aabb, depth: u32, flip: bool, force_moving: bool, pad: f64,
                        unbounded_leaves: bool) -> Result<(i32, Aabb), LowerError> {
-        fn flatten(list: &[Rc<HittableDesc>], flip: bool, out: &mut Vec<(Rc<HittableDesc>, bool)>) {
-            for m in list {
-                let mut f = flip;
-                let h = strip_flips(m, &mut f);
-                if let HittableDesc::List { list: sub } = &**h {
-                    flatten(sub, f, out);
-                } else {
-                    out.push((h.clone(), f));
-                }
-            }
-        }
         let is_sphere = |h: &Rc<HittableDesc>| {
             let mut d = false;
             matches!(&**strip_wrappers(h, &mut d, None), HittableDesc::Sphere { .. } | HittableDesc::MovingSphere { .. })
         };
         let mut members = Vec::new();
-        flatten(list, flip, &mut members);
+        flatten_list(list, flip, &mut members);
         if members.is_empty() {
             return Err(LowerError::Panic("BVHNode over an empty HittableList: no bounding box (bvh.rs:30)".into()));
         }
@@ -932,9 +951,56 @@ impl SceneBuilder {
         self.lower_item_deferred(top, None)
     }
 
+    /// The members of a list with media that was a child of a BVHNode, in scan order, then the terminator (rt_host.cpp
+    /// lower_scan_group; rtmi.h LISTSCAN)
+    fn lower_scan_group(&mut self, top: &Rc<HittableDesc>, deferred: &DeferredMedium) -> Result<(), LowerError> {
+        let mut flip = deferred.flip;
+        let list = match &**strip_flips(top, &mut flip) {
+            HittableDesc::List { list } => list,
+            _ => return Err(LowerError::Panic("lower_scan_group: not a list".into())),
+        };
+        let mut all = Vec::new();
+        flatten_list(list, flip, &mut all);
+        let mut members = Vec::new();
+        for m in all {
+            if !is_medium_child(&m.0) && never_hit(&m.0) {
+                continue; // no hit, no draw: left out of the scan
+            }
+            let mut d = false;
+            if matches!(&**strip_wrappers(&m.0, &mut d, None), HittableDesc::Bvh { .. }) {
+                return Err(LowerError::Unsupported("a BVHNode as a member of a HittableList that holds media and is a BVH child is not lowered".into()));
+            }
+            members.push(m);
+        }
+        for (k, m) in members.iter().enumerate() {
+            let dm = DeferredMedium {
+                gate: deferred.gate,
+                chain_first: deferred.chain_first,
+                chain_count: deferred.chain_count,
+                save_t0: deferred.save_t0 && k == 0,
+                rank: deferred.rank,
+                flip: m.1,
+                scan: RTMI_ITEMFLAG_LISTSCAN_MEMBER | (if k == 0 { RTMI_ITEMFLAG_LISTSCAN_BEGIN } else { 0 }),
+            };
+            self.lower_item_deferred(&m.0, Some(dm))?;
+        }
+        let mut end = zero_item();
+        end.kind = RTMI_ITEM_LIST;
+        end.first = deferred.rank; // leaves of the enclosing tree that precede the list in traversal order (ties)
+        end.flags = RTMI_ITEMFLAG_DEFERRED | RTMI_ITEMFLAG_LISTSCAN_END;
+        self.out.items.push(end);
+        self.run_item = None;
+        Ok(())
+    }
+
     /// `deferred`: a medium that was a child of a BVHNode — it sits inside the transforms of that BVH item (a copy of them
     /// first), is gated by the box of that node and evaluated against the t_max the BVH was entered with (rtmi.h)
     fn lower_item_deferred(&mut self, top: &Rc<HittableDesc>, deferred: Option<DeferredMedium>) -> Result<(), LowerError> {
+        if let Some(d) = &deferred {
+            if d.scan == 0 && is_media_list_child(top) {
+                return self.lower_scan_group(top, d);
+            }
+        }
         let mut it = zero_item();
         it.xform_first = self.out.xforms.len() as i32;
         let (mut flip, mut medium, mut nested) = (false, false, false);
@@ -1003,9 +1069,10 @@ impl SceneBuilder {
         }
         if let Some(d) = &deferred {
             let is_bvh = matches!(&**h, HittableDesc::Bvh { .. });
-            if !medium && !is_bvh {
-                return Err(LowerError::Panic("lower_item: a deferred item must be a ConstantMedium or an instanced BVHNode".into()));
+            if !medium && !is_bvh && d.scan == 0 {
+                return Err(LowerError::Panic("lower_item: a deferred item must be a ConstantMedium, an instanced BVHNode or a member of a list scan".into()));
             }
+            it.flags |= d.scan;
             if d.chain_count > 15 || it.xform_count > 15 {
                 return Err(LowerError::Unsupported("a deferred child of a BVHNode inside more than 15 Traslate/Rotate wrappers".into()));
             }
@@ -1033,7 +1100,7 @@ impl SceneBuilder {
                 let pend = std::mem::take(&mut self.pending_media);
                 self.run_item = None;
                 for (k, pm) in pend.iter().enumerate() {
-                    let dm = DeferredMedium { gate: pm.gate, chain_first: it.xform_first, chain_count: it.xform_count, save_t0: k == 0 && deferred.is_none(), rank: pm.rank, flip: pm.flip != flip };
+                    let dm = DeferredMedium { gate: pm.gate, chain_first: it.xform_first, chain_count: it.xform_count, save_t0: k == 0 && deferred.is_none(), rank: pm.rank, flip: pm.flip != flip, scan: 0 };
                     self.lower_item_deferred(&pm.obj, Some(dm))?;
                 }
                 return Ok(());
@@ -1099,7 +1166,7 @@ impl SceneBuilder {
                 let prim = h;
                 // A run of consecutive plain primitives of the world list (no transform, no medium) becomes ONE list
                 // item: scanned in order with the shrinking t_max exactly as items are (hittable.rs:37-47).
-                if !medium && it.xform_count == 0 {
+                if !medium && it.xform_count == 0 && deferred.is_none() {
                     if never_hit(prim) {
                         return Ok(()); // left out of the scan; the run goes on
                     }
@@ -1125,11 +1192,14 @@ impl SceneBuilder {
             }
         }
         self.run_item = None;
-        if let (Some(d), false) = (&deferred, medium) {
+        if let (Some(d), true) = (&deferred, !medium && it.kind == RTMI_ITEM_BVH) {
             it.count = d.rank; // leaves of the enclosing tree that precede it in traversal order (ties)
         }
-        if let (Some(d), true) = (&deferred, medium && it.kind == RTMI_ITEM_LIST) {
-            // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
+        if let (Some(d), true) = (&deferred, it.kind == RTMI_ITEM_LIST) {
+            // the gate: the box of the BVHNode the medium (the list) was a child of, with every primitive (rtmi.h)
+            if it.count < 1 {
+                return Err(LowerError::Unsupported("a member of a list scan without a primitive that can be hit".into()));
+            }
             let (gmn, gmx) = put_box(&d.gate);
             for q in it.first..it.first + it.count {
                 let g = &mut self.out.prim_gate[q as usize * 8..q as usize * 8 + 8];
@@ -1153,7 +1223,7 @@ impl SceneBuilder {
             self.out.items.push(it);
             let pend = std::mem::take(&mut self.pending_media);
             for pm in pend.iter() {
-                let dm = DeferredMedium { gate: pm.gate, chain_first, chain_count, save_t0: false, rank: pm.rank, flip: pm.flip != flip };
+                let dm = DeferredMedium { gate: pm.gate, chain_first, chain_count, save_t0: false, rank: pm.rank, flip: pm.flip != flip, scan: 0 };
                 self.lower_item_deferred(&pm.obj, Some(dm))?;
             }
             return Ok(());

@@ -68,6 +68,10 @@ pub const RTMI_ITEMFLAG_SAVE_T0: u32 = 4;
 pub const RTMI_ITEMFLAG_DEFERRED: u32 = 8;
 /// a ConstantMedium whose boundary is a ConstantMedium: the inner density travels in an RTMI_XF_INNER_MEDIUM record
 pub const RTMI_ITEMFLAG_NESTED_MEDIUM: u32 = 16;
+/// a HittableList with media among its members as a BVH child: a group of DEFERRED member items and a terminator (rtmi.h)
+pub const RTMI_ITEMFLAG_LISTSCAN_BEGIN: u32 = 32;
+pub const RTMI_ITEMFLAG_LISTSCAN_MEMBER: u32 = 64;
+pub const RTMI_ITEMFLAG_LISTSCAN_END: u32 = 128;
 /// DEFERRED items: bits 12..15 = number of leading transforms that belong to the enclosing BVH item
 pub const RTMI_ITEMFLAG_GATE_OUTER_SHIFT: u32 = 12;
 pub const RTMI_NO_CHILD: i32 = 0x7fff_ffff;

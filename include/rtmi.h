@@ -188,6 +188,19 @@ enum { RTMI_ITEM_LIST = 0, RTMI_ITEM_BVH = 1 };
  * in an RTMI_XF_INNER_MEDIUM record behind their chain; material and density of the item are the OUTER medium's (the hit
  * record is its own, medium.rs:47-54).  One level, no wrappers between the two media. */
 #define RTMI_ITEMFLAG_NESTED_MEDIUM 16u
+/* A HittableList with media among its members as a child of a BVHNode.  The list's scan (hittable.rs:37-47) starts from the
+ * t_max the BVH was entered with (T0) and hands every member the closest hit of the members before it; a medium member draws
+ * whenever its boundary interval clamped to THAT is not empty; the BVH then folds the list's result like any child's
+ * (bvh.rs:75-81).  Lowered as a group of DEFERRED items behind the BVH item, in member order: every member (a primitive,
+ * also inside its own Traslate / Rotate, or a medium) is an item with LISTSCAN_MEMBER — evaluated with t_max = the scan's
+ * closest hit so far, which LISTSCAN_BEGIN on the first member resets to T0; its gate is the box of the node that holds the
+ * list, like every deferred item's — and the group ends with a terminator: kind LIST, count 0, LISTSCAN_END, `first` = the
+ * number of primitive leaves of the enclosing tree that precede the list in traversal order; there the scan's result meets
+ * the closest hit so far (closer wins; an exact tie of a primitive goes to the later child by that number; of a medium, to
+ * the other side). */
+#define RTMI_ITEMFLAG_LISTSCAN_BEGIN 32u
+#define RTMI_ITEMFLAG_LISTSCAN_MEMBER 64u
+#define RTMI_ITEMFLAG_LISTSCAN_END 128u
 #define RTMI_ITEMFLAG_GATE_OUTER_SHIFT 12
 typedef struct {
     int32_t kind;

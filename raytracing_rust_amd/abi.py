@@ -39,6 +39,7 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0,
 PRIM_SPHERE, PRIM_MSPHERE, PRIM_RECT, PRIM_CUBE = 0, 1, 2, 3
 ITEM_LIST, ITEM_BVH = 0, 1
 ITEMFLAG_FLIP, ITEMFLAG_MEDIUM, ITEMFLAG_SAVE_T0, ITEMFLAG_DEFERRED, ITEMFLAG_NESTED_MEDIUM = 1, 2, 4, 8, 16
+ITEMFLAG_LISTSCAN_BEGIN, ITEMFLAG_LISTSCAN_MEMBER, ITEMFLAG_LISTSCAN_END = 32, 64, 128
 RTMI_ITEMFLAG_GATE_OUTER_SHIFT = 12  # DEFERRED items: how many leading transforms belong to the enclosing BVH item (bits 12..15)
 XF_TRANSLATE, XF_ROTATE_X, XF_ROTATE_Y, XF_ROTATE_Z, XF_GATE_MIN, XF_GATE_MAX, XF_INNER_MEDIUM = 0, 1, 2, 3, 4, 5, 6
 

@@ -251,6 +251,7 @@ static int validate(const rtmi_scene_desc *d) {
         }
         return RTMI_OK;
     };
+    bool scan_open = false;
     for (uint32_t i = 0; i < d->n_items; i++) {
         const rtmi_item &it = d->items[i];
         if (it.kind == RTMI_ITEM_LIST) {
@@ -283,11 +284,30 @@ static int validate(const rtmi_scene_desc *d) {
             if (!(it.flags & RTMI_ITEMFLAG_MEDIUM) || at >= d->n_xforms || d->xforms[at].kind != RTMI_XF_INNER_MEDIUM)
                 return fail(RTMI_ERR_INVALID, "a NESTED_MEDIUM item must be a MEDIUM with its RTMI_XF_INNER_MEDIUM record behind its transform chain");
         }
+        { // list scans that were children of a BVHNode (rtmi.h): BEGIN on the first member, members only inside, one terminator
+            const uint32_t ls = it.flags & (RTMI_ITEMFLAG_LISTSCAN_BEGIN | RTMI_ITEMFLAG_LISTSCAN_MEMBER | RTMI_ITEMFLAG_LISTSCAN_END);
+            if (ls && !(it.flags & RTMI_ITEMFLAG_DEFERRED)) return fail(RTMI_ERR_INVALID, "a LISTSCAN item must be DEFERRED");
+            if (ls & RTMI_ITEMFLAG_LISTSCAN_END) {
+                if (ls != RTMI_ITEMFLAG_LISTSCAN_END || !scan_open || it.kind != RTMI_ITEM_LIST || it.count != 0 || it.first < 0 ||
+                    (it.flags & (RTMI_ITEMFLAG_MEDIUM | RTMI_ITEMFLAG_SAVE_T0)))
+                    return fail(RTMI_ERR_INVALID, "the terminator of a list scan is a LIST item of no primitives behind its members, `first` = its position in the tree");
+                scan_open = false;
+                continue;
+            }
+            if (ls & RTMI_ITEMFLAG_LISTSCAN_BEGIN) {
+                if (scan_open || !(ls & RTMI_ITEMFLAG_LISTSCAN_MEMBER)) return fail(RTMI_ERR_INVALID, "LISTSCAN_BEGIN inside an open list scan, or not on a member");
+                scan_open = true;
+            }
+            if (scan_open != ((ls & RTMI_ITEMFLAG_LISTSCAN_MEMBER) != 0u))
+                return fail(RTMI_ERR_INVALID, "every item between LISTSCAN_BEGIN and the terminator is a LISTSCAN_MEMBER, and no other is");
+            if ((ls & RTMI_ITEMFLAG_LISTSCAN_MEMBER) && it.kind == RTMI_ITEM_BVH && !(it.flags & RTMI_ITEMFLAG_MEDIUM))
+                return fail(RTMI_ERR_UNSUPPORTED, "a BVH as a member of a list scan is supported as a medium's boundary only");
+        }
         if (it.flags & RTMI_ITEMFLAG_DEFERRED) { // a medium or an instanced subtree that was a child of a BVHNode (rtmi.h)
             const int32_t G = (int32_t)((it.flags >> RTMI_ITEMFLAG_GATE_OUTER_SHIFT) & 15u);
             if (it.kind == RTMI_ITEM_LIST) {
-                if (!(it.flags & RTMI_ITEMFLAG_MEDIUM) || it.count < 1 || !d->prim_gate)
-                    return fail(RTMI_ERR_INVALID, "a DEFERRED item of kind LIST must be a MEDIUM with at least one primitive, and prim_gate must be given");
+                if (!(it.flags & (RTMI_ITEMFLAG_MEDIUM | RTMI_ITEMFLAG_LISTSCAN_MEMBER)) || it.count < 1 || !d->prim_gate)
+                    return fail(RTMI_ERR_INVALID, "a DEFERRED item of kind LIST must be a MEDIUM or a member of a list scan, with at least one primitive, and prim_gate must be given");
             } else {
                 if (G > it.xform_count || (uint32_t)(it.xform_first + it.xform_count) + 2u > d->n_xforms ||
                     d->xforms[it.xform_first + it.xform_count].kind != RTMI_XF_GATE_MIN || d->xforms[it.xform_first + it.xform_count + 1].kind != RTMI_XF_GATE_MAX)
@@ -297,6 +317,7 @@ static int validate(const rtmi_scene_desc *d) {
                 return fail(RTMI_ERR_INVALID, "a DEFERRED medium's enclosing transforms must be among those that wrap the medium");
         }
     }
+    if (scan_open) return fail(RTMI_ERR_INVALID, "a list scan without its terminator");
     for (uint32_t i = 0; i < d->n_materials; i++) {
         const rtmi_material &m = d->materials[i];
         if (m.kind < 0 || m.kind > RTMI_MAT_ISOTROPIC) return fail(RTMI_ERR_INVALID, "bad material kind");
@@ -361,7 +382,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
         std::vector<rtmi_item> items(d->items, d->items + d->n_items);
         for (rtmi_item &it : items) {
             it.flags &= (RTMI_ITEMFLAG_FLIP | RTMI_ITEMFLAG_MEDIUM | (15u << RTMI_ITEMFLAG_MEDIUM_OUTER_SHIFT) | RTMI_ITEMFLAG_SAVE_T0 |
-                         RTMI_ITEMFLAG_DEFERRED | (15u << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) | RTMI_ITEMFLAG_NESTED_MEDIUM);
+                         RTMI_ITEMFLAG_DEFERRED | (15u << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) | RTMI_ITEMFLAG_NESTED_MEDIUM |
+                         RTMI_ITEMFLAG_LISTSCAN_BEGIN | RTMI_ITEMFLAG_LISTSCAN_MEMBER | RTMI_ITEMFLAG_LISTSCAN_END);
             if ((it.flags & RTMI_ITEMFLAG_MEDIUM) && !(it.flags & (RTMI_ITEMFLAG_DEFERRED | RTMI_ITEMFLAG_NESTED_MEDIUM)) && it.kind == RTMI_ITEM_LIST && it.count == 1 &&
                 d->prim_meta[it.first].type == RTMI_PRIM_SPHERE &&
                 ((d->prim_meta[it.first].flags >> RTMI_PRIMFLAG_XF_COUNT_SHIFT) & RTMI_PRIM_XF_MAX) == 0u) {

@@ -75,11 +75,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                 float t0_saved = RTMI_FLT_MAX; // the closest hit before a BVH item whose media / instanced-subtree children follow as DEFERRED items
                 int grp_first = 0x7fffffff;    // ... the index of that item (or of the first deferred one), and whether it is the enclosing tree
                 bool grp_tree = false;
+                ListScan ls; // a list with media that was a child of a BVHNode (rtmi.h, LISTSCAN)
+                ls.cl = RTMI_FLT_MAX; ls.item = -1; ls.pf = 0; ls.medium = false; ls.has = false;
                 for (uint32_t it = 0; it < sc.n_items; it++) {
                     const rtmi_item I = sc.items[it].it;
                     if (I.flags & RTMI_ITEMFLAG_SAVE_T0) {
                         t0_saved = closest; grp_first = (int)it; grp_tree = I.kind == RTMI_ITEM_BVH && !(I.flags & RTMI_ITEMFLAG_DEFERRED);
                     }
+                    if (I.flags & RTMI_ITEMFLAG_LISTSCAN_END) { // the terminator: the scan's result meets the closest hit so far
+                        listscan_fold(ls, I.first, closest, best_item, best_pf, best_medium, grp_first, grp_tree);
+                        continue;
+                    }
+                    if (I.flags & RTMI_ITEMFLAG_LISTSCAN_BEGIN) { ls.cl = t0_saved; ls.has = false; }
+                    const bool scan = (I.flags & RTMI_ITEMFLAG_LISTSCAN_MEMBER) != 0u;
                     RayF R = W;
                     if (I.xform_count > 0) {
                         if (xform_ray(sc.xforms, I.xform_first, I.xform_count, R.o, R.d)) ray_derive(R);
@@ -88,10 +96,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                     if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                         float t;
                         int pf;
-                        if (I.flags & RTMI_ITEMFLAG_DEFERRED) { // an instanced subtree that was a child of a BVHNode (rtmi.h)
+                        if (scan) { // a primitive member of the list scan: t_max = the scan's closest hit so far
+                            if (deferred_gate(sc, I, W, P.t_min, t0_saved) &&
+                                geom_query<FAST, PROF>(sc, I, R, pa.rtime, P.t_min, ls.cl, stack, t, pf, prof, slot)) {
+                                ls.cl = t; ls.item = (int)it; ls.pf = pf; ls.medium = false; ls.has = true;
+                            }
+                        } else if (I.flags & RTMI_ITEMFLAG_DEFERRED) { // an instanced subtree that was a child of a BVHNode (rtmi.h)
                             if (deferred_gate(sc, I, W, P.t_min, t0_saved) &&
                                 geom_query<FAST, PROF>(sc, I, R, pa.rtime, P.t_min, t0_saved, stack, t, pf, prof, slot) &&
-                                deferred_bvh_wins(I, t, closest, best_item, best_pf, grp_first, grp_tree)) {
+                                deferred_bvh_wins(I.count, t, closest, best_item, best_pf, grp_first, grp_tree)) {
                                 closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                             }
                         } else if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, P.t_min, closest, stack, t, pf, prof, slot)) {
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                         // a medium that was a child of a BVHNode (rtmi.h, DEFERRED): reached through its parent's box, its
                         // interval clamped to the t_max the BVH was entered with, accepted when closer than the tree's hit
                         const bool dfr = (I.flags & RTMI_ITEMFLAG_DEFERRED) != 0u;
-                        const float qmax = dfr ? t0_saved : closest;
+                        const float qmax = scan ? ls.cl : (dfr ? t0_saved : closest);
                         if (!dfr || deferred_gate(sc, I, W, P.t_min, t0_saved)) {
                         if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, stack, t1, pf, prof, slot)) {
                             if (geom_query<FAST, PROF>(sc, I, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, stack, t2, pf, prof, slot)) {
@@ -113,7 +126,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
                                     // the inner medium returned no hit to one of the outer medium's two queries
                                 } else
                                 if (medium_sample(t1, t2, P.t_min, qmax, dn, I.neg_inv_density, g, k0, k1, tm)) {
-                                    if (!dfr || tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }
+                                    if (scan) { ls.cl = tm; ls.item = (int)it; ls.medium = true; ls.has = true; }
+                                    else if (!dfr || tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }
                                 }
                             }
                         }
@@ -235,11 +249,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             float t0_saved = RTMI_FLT_MAX; // INST: the closest hit before a BVH item whose media / instanced-subtree children follow as DEFERRED items
             int grp_first = 0x7fffffff;    // ... the index of that item (or of the first deferred one), and whether it is the enclosing tree
             bool grp_tree = false;
+            ListScan ls; // INST: a list with media that was a child of a BVHNode (rtmi.h, LISTSCAN)
+            ls.cl = RTMI_FLT_MAX; ls.item = -1; ls.pf = 0; ls.medium = false; ls.has = false;
             for (uint32_t it = 0; it < n_items; it++) { // executed by all 64 lanes
                 const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
                 if (INST && (I.flags & RTMI_ITEMFLAG_SAVE_T0)) {
                     t0_saved = closest; grp_first = (int)it; grp_tree = I.kind == RTMI_ITEM_BVH && !(I.flags & RTMI_ITEMFLAG_DEFERRED);
                 }
+                if (INST && (I.flags & RTMI_ITEMFLAG_LISTSCAN_END)) { // wave-uniform: the terminator of a list scan
+                    if (need) listscan_fold(ls, I.first, closest, best_item, best_pf, best_medium, grp_first, grp_tree);
+                    continue;
+                }
+                if (INST && (I.flags & RTMI_ITEMFLAG_LISTSCAN_BEGIN)) { ls.cl = t0_saved; ls.has = false; }
+                const bool scan = INST && (I.flags & RTMI_ITEMFLAG_LISTSCAN_MEMBER) != 0u; // wave-uniform
                 RayF R = W;
                 if (I.xform_count > 0) { // both transforms of a chain of two in ONE scalar fetch (they follow the item record)
                     struct XPair { rtmi_xform x0, x1; };
@@ -250,10 +272,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                     float t;
                     int pf;
+                    if (scan) { // a primitive member of the list scan: t_max = the scan's closest hit so far
+                        const bool reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
+                        if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, reach, R, pa.rtime, t_min, ls.cl, cw, t, pf, overflow, prof, slot)) {
+                            ls.cl = t; ls.item = (int)it; ls.pf = pf; ls.medium = false; ls.has = true;
+                        }
+                    } else
                     if (INST && (I.flags & RTMI_ITEMFLAG_DEFERRED)) { // wave-uniform: an instanced subtree that was a child of a BVHNode (rtmi.h)
                         const bool reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
                         if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, reach, R, pa.rtime, t_min, t0_saved, cw, t, pf, overflow, prof, slot) &&
-                            deferred_bvh_wins(I, t, closest, best_item, best_pf, grp_first, grp_tree)) {
+                            deferred_bvh_wins(I.count, t, closest, best_item, best_pf, grp_first, grp_tree)) {
                             closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                         }
                     } else
@@ -283,8 +311,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                             if (reach && h1 && h2) h1 = nested_medium_interval(sc, I, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), g, k0, k1, t1, t2);
                         }
                         if (dfr) { // its interval ends at the t_max the BVH was entered with; its hit must beat what the tree found
-                            if (reach && h1 && h2 && medium_sample(t1, t2, t_min, t0_saved, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
-                                if (tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }
+                            if (reach && h1 && h2 && medium_sample(t1, t2, t_min, scan ? ls.cl : t0_saved, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
+                                if (scan) { ls.cl = tm; ls.item = (int)it; ls.medium = true; ls.has = true; }
+                                else if (tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }
                             }
                             h1 = false; // done
                         }

@@ -278,7 +278,7 @@ __device__ __forceinline__ bool deferred_gate(const DevScene &sc, const rtmi_ite
     RayF Rg = W;
     if (G > 0 && xform_ray(sc.xforms, I.xform_first, G, Rg.o, Rg.d)) ray_derive(Rg);
     float4 g0, g1;
-    if (I.kind == RTMI_ITEM_LIST) { // a medium around primitives: the gate of its first boundary primitive
+    if (I.kind == RTMI_ITEM_LIST) { // a medium around primitives (a primitive of a list scan): the gate of its first primitive
         const float4 *rec = sc.leaf_rec + (size_t)I.first * 5;
         g0 = rec[3]; g1 = rec[4];
     } else { // geometry = a BVHNode (an instanced subtree, a medium's boundary): the two records behind its chain ({kind, x, y, z})
@@ -288,16 +288,29 @@ __device__ __forceinline__ bool deferred_gate(const DevScene &sc, const rtmi_ite
     return aabb_hit(g0.x, g0.y, g0.z, g1.x, g1.y, g1.z, Rg, t_min, t0);
 }
 // A hit of a DEFERRED BVH item (an instanced subtree that was a child of a BVHNode) against the closest hit so far: the
-// fold of bvh.rs:75-81 — closer wins, an exact tie goes to the LATER child — between the subtree (position: I.count leaves
-// of the enclosing tree precede it) and whatever holds the closest hit: something before the group (the list scan accepts
+// fold of bvh.rs:75-81 — closer wins, an exact tie goes to the LATER child — between the subtree (position: `rank` leaves
+// of the enclosing tree precede it; the same for the result of a list scan that was a child of a BVHNode, LISTSCAN_END) and whatever holds the closest hit: something before the group (the list scan accepts
 // every hit its t_max lets through, hittable.rs:40-44), a leaf of the enclosing tree (later iff its index >= I.count), or
 // an earlier deferred item of the group (earlier).
-__device__ __forceinline__ bool deferred_bvh_wins(const rtmi_item &I, float t, float closest, int best_item, int best_pf, int grp_first,
+__device__ __forceinline__ bool deferred_bvh_wins(int rank, float t, float closest, int best_item, int best_pf, int grp_first,
                                                   bool grp_tree) {
     if (t < closest) return true;
     if (t != closest) return false;
-    if (grp_tree && best_item == grp_first) return (best_pf >> 3) < I.count; // a leaf of the enclosing tree holds the closest hit
+    if (grp_tree && best_item == grp_first) return (best_pf >> 3) < rank; // a leaf of the enclosing tree holds the closest hit
     return true; // something before the group, or an earlier deferred item of it
+}
+// The scan of a HittableList that was a child of a BVHNode and holds media (LISTSCAN items, rtmi.h): its closest hit so far
+// and who holds it; `fold` at the terminator item.
+struct ListScan {
+    float cl;
+    int item, pf;
+    bool medium, has;
+};
+__device__ __forceinline__ void listscan_fold(const ListScan &ls, int rank, float &closest, int &best_item, int &best_pf, bool &best_medium,
+                                              int grp_first, bool grp_tree) {
+    if (!ls.has) return;
+    const bool wins = ls.medium ? ls.cl < closest : deferred_bvh_wins(rank, ls.cl, closest, best_item, best_pf, grp_first, grp_tree);
+    if (wins) { closest = ls.cl; best_item = ls.item; best_pf = ls.pf; best_medium = ls.medium; }
 }
 template <typename RngT>
 __device__ __forceinline__ bool medium_sample(float t1, float t2, float t_min, float closest, float dn,

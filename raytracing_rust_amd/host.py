@@ -114,6 +114,7 @@ class Scene:
             "textures": [d.textures[i] for i in range(d.n_textures)],
             "n_perlin": d.n_perlin, "n_images": d.n_images, "image_bytes": d.image_bytes,
             "max_bvh_depth": d.max_bvh_depth,
+            "prim_gate": view(d.prim_gate, d.n_prims * 8, np.float32).reshape(-1, 8) if d.prim_gate else np.zeros((0, 8), np.float32),
         }
         return out
 

@@ -797,7 +797,27 @@ static bool is_instanced_bvh_child(const Hittable *h) {
     const Hittable *core = strip_wrappers(h, dummy, &chain);
     return dynamic_cast<const BVHNode *>(core) != nullptr && !chain.empty();
 }
-static bool is_deferred_child(const Hittable *h) { return is_medium_child(h) || is_instanced_bvh_child(h); }
+// A HittableList with media among its members (nested lists and FlipNormals looked through) as a child of a BVHNode: its
+// scan hands every member the closest hit of the members before it, starting from the t_max the BVH was entered with, so
+// the whole list leaves the tree — a group of DEFERRED member items and a terminator behind the BVH item (rtmi.h, LISTSCAN).
+static bool list_holds_media(const HittableList &l) {
+    for (const auto &m : l.items()) {
+        bool d = false;
+        const Hittable *s = strip_flips(m.get(), d);
+        if (auto sub = dynamic_cast<const HittableList *>(s)) {
+            if (list_holds_media(*sub)) return true;
+        } else if (is_medium_child(s)) {
+            return true;
+        }
+    }
+    return false;
+}
+static bool is_media_list_child(const Hittable *h) {
+    bool d = false;
+    auto l = dynamic_cast<const HittableList *>(strip_flips(h, d));
+    return l != nullptr && list_holds_media(*l);
+}
+static bool is_deferred_child(const Hittable *h) { return is_medium_child(h) || is_instanced_bvh_child(h) || is_media_list_child(h); }
 static bool has_prims(const Hittable *h) {
     bool dummy = false;
     const Hittable *s = strip_flips(h, dummy);
@@ -1185,7 +1205,37 @@ int32_t SceneBuilder::collapse_alt(int32_t ref, uint32_t depth, int height) {
     return id;
 }
 
+// The members of a list with media that was a child of a BVHNode, in scan order, then the terminator (rtmi.h, LISTSCAN).
+void SceneBuilder::lower_scan_group(const Hittable &top, const DeferredMedium &deferred) {
+    bool flip = deferred.flip;
+    const auto *list = dynamic_cast<const HittableList *>(strip_flips(&top, flip));
+    std::vector<std::pair<const Hittable *, bool>> all, members;
+    flatten_list_leaf(*list, flip, all);
+    for (const auto &m : all) {
+        if (!is_medium_child(m.first) && never_hit(m.first)) continue; // no hit, no draw: left out of the scan
+        bool d = false;
+        if (dynamic_cast<const BVHNode *>(strip_wrappers(m.first, d, nullptr)))
+            throw Unsupported("a BVHNode as a member of a HittableList that holds media and is a BVH child is not lowered");
+        members.push_back(m);
+    }
+    for (size_t k = 0; k < members.size(); k++) {
+        DeferredMedium dm = deferred;
+        dm.flip = members[k].second;
+        dm.save_t0 = deferred.save_t0 && k == 0;
+        dm.scan = RTMI_ITEMFLAG_LISTSCAN_MEMBER | (k == 0 ? RTMI_ITEMFLAG_LISTSCAN_BEGIN : 0u);
+        lower_item(*members[k].first, &dm);
+    }
+    rtmi_item end{};
+    end.kind = RTMI_ITEM_LIST;
+    end.first = deferred.rank; // leaves of the enclosing tree that precede the list in traversal order (ties)
+    end.alt_first = -1;
+    end.flags = RTMI_ITEMFLAG_DEFERRED | RTMI_ITEMFLAG_LISTSCAN_END;
+    out.items.push_back(end);
+    run_item_ = -1;
+}
+
 void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferred) {
+    if (deferred && deferred->scan == 0u && is_media_list_child(&top)) { lower_scan_group(top, *deferred); return; }
     rtmi_item it{};
     it.alt_first = -1;
     it.xform_first = (int32_t)out.xforms.size();
@@ -1244,7 +1294,8 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
     if (!deferred) push_inner_medium();
     if (deferred) {
         const bool is_bvh = dynamic_cast<const BVHNode *>(h) != nullptr;
-        if (!medium && !is_bvh) throw Panic("lower_item: a deferred item must be a ConstantMedium or an instanced BVHNode");
+        if (!medium && !is_bvh && deferred->scan == 0u) throw Panic("lower_item: a deferred item must be a ConstantMedium, an instanced BVHNode or a member of a list scan");
+        it.flags |= deferred->scan;
         if (deferred->chain_count > 15 || it.xform_count > 15) throw Unsupported("a deferred child of a BVHNode inside more than 15 Traslate/Rotate wrappers");
         it.flags |= RTMI_ITEMFLAG_DEFERRED | ((uint32_t)deferred->chain_count << RTMI_ITEMFLAG_GATE_OUTER_SHIFT) |
                     (deferred->save_t0 ? RTMI_ITEMFLAG_SAVE_T0 : 0u);
@@ -1322,7 +1373,7 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
         // A run of consecutive plain primitives of the world list (no transform, no medium) becomes ONE list
         // item: the device scans its primitives in order with the shrinking t_max exactly as it scans items
         // (hittable.rs:37-47), without the per-item overhead.  FlipNormals goes to the primitive's flag.
-        if (!medium && it.xform_count == 0) {
+        if (!medium && it.xform_count == 0 && !deferred) {
             if (never_hit(h)) return; // left out of the scan; the run goes on
             if (run_item_ >= 0) {
                 rtmi_item &run = out.items[(size_t)run_item_];
@@ -1345,8 +1396,9 @@ void SceneBuilder::lower_item(const Hittable &top, const DeferredMedium *deferre
         it.count = 1;
     }
     run_item_ = -1;
-    if (deferred && !medium) it.count = deferred->rank; // leaves of the enclosing tree that precede it in traversal order (ties)
-    if (deferred && medium && it.kind == RTMI_ITEM_LIST) { // the gate: the box of the BVHNode the medium was a child of, with every boundary primitive (rtmi.h)
+    if (deferred && !medium && it.kind == RTMI_ITEM_BVH) it.count = deferred->rank; // leaves of the enclosing tree that precede it in traversal order (ties)
+    if (deferred && it.kind == RTMI_ITEM_LIST) { // the gate: the box of the BVHNode the medium (the list) was a child of, with every primitive (rtmi.h)
+        if (it.count < 1) throw Unsupported("a member of a list scan without a primitive that can be hit");
         float gmn[3], gmx[3];
         put_box(gmn, gmx, deferred->gate);
         for (int32_t q = it.first; q < it.first + it.count; q++) {

@@ -364,7 +364,8 @@ class SceneBuilder {
   private:
     // a ConstantMedium that was a child of a BVHNode, lowered as an item of its own behind the BVH item (rt_host.cpp)
     struct PendingMedium { const Hittable *obj; AABB gate; int32_t rank; bool flip; }; // rank: primitives pushed before it (in-order position)
-    struct DeferredMedium { AABB gate; int32_t chain_first; int32_t chain_count; bool save_t0; int32_t rank; bool flip; };
+    struct DeferredMedium { AABB gate; int32_t chain_first; int32_t chain_count; bool save_t0; int32_t rank; bool flip; uint32_t scan = 0u; }; // scan: LISTSCAN flags of a member
+    void lower_scan_group(const Hittable &top, const DeferredMedium &deferred);
     std::vector<PendingMedium> pending_media_;
     void collect_media(const Hittable *h, const BVHNode &parent, bool flip_all);
     void lower_item(const Hittable &h, const DeferredMedium *deferred = nullptr);

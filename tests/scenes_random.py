@@ -134,6 +134,26 @@ def random_scene(api, seed, only=None, instanced=False):
                     if rng2.random() < 0.3:
                         md = api.Traslate(md, rng2.uniform(-1.0, 1.0, 3))
                     meds.append(md)
+                if rng2.random() < 0.35:
+                    # a HittableList WITH MEDIA as one object of the BVH (tests/test_media_in_bvh.py, world_media_in_lists_in_bvh):
+                    # the first medium together with up to three of the primitives, before and behind it in the scan,
+                    # sometimes inside a nested (flipped) list
+                    grp = api.HittableList()
+                    take = [objs.pop(int(rng2.integers(0, len(objs)))) for _ in range(min(len(objs) - 1, int(rng2.integers(0, 4))))]
+                    cut = int(rng2.integers(0, len(take) + 1))
+                    for q in take[:cut]:
+                        grp.push(q)
+                    if rng2.random() < 0.3:
+                        sub = api.HittableList()
+                        sub.push(meds[0])
+                        if take[cut:]:
+                            sub.push(take[cut])
+                        grp.push(api.FlipNormals(sub) if rng2.random() < 0.5 else sub)
+                    else:
+                        grp.push(meds[0])
+                    for q in take[cut:]:
+                        grp.push(q)
+                    meds[0] = api.FlipNormals(grp) if rng2.random() < 0.2 else grp
                 if n == 1 and rng2.random() < 0.5:
                     objs = meds  # nothing but media
                 else:

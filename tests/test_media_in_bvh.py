@@ -108,6 +108,78 @@ def world_nested_media(api):
     return w
 
 
+def world_media_in_lists_in_bvh(api):
+    """A HittableList WITH MEDIA among its members as a child of a BVHNode: the list's scan hands every member the closest
+    hit of the members before it (from the t_max the BVH was entered with), so a medium behind a nearer member of the SAME
+    list draws less often than one that sits in the tree by itself.  Primitives before and after the medium, a nested list,
+    flips, members with their own transforms, two media in one list, a nested medium, the list twice under a one-element
+    node, and everything once more inside Traslate(Rotate(..))."""
+    api.seed_scene_rng(5)
+    lam = lambda r, g, b: api.Lambertian(api.SolidTexture(r, g, b))  # noqa: E731
+    glass = api.Dielectric(1.5)
+    w = api.HittableList()
+    w.push(api.Rect(api.PLANE_ZX, -9.0, -9.0, 9.0, 9.0, -1.0, lam(0.6, 0.6, 0.6)))
+    w.push(api.Sphere((0.0, 10.0, 2.0), 3.0, api.DiffuseLight(api.SolidTexture(5.0, 5.0, 5.0))))
+
+    def group(cx, cy, cz, nested=False):
+        g = api.HittableList()
+        g.push(api.Sphere((cx - 0.5, cy, cz + 0.6), 0.45, lam(0.9, 0.3, 0.3)))      # in front of the medium: shortens its interval
+        med = api.ConstantMedium(api.Sphere((cx, cy, cz), 0.9, glass), 2.5, api.SolidTexture(0.3, 0.9, 0.4))
+        if nested:
+            med = api.ConstantMedium(api.ConstantMedium(api.Sphere((cx, cy, cz), 0.9, glass), 0.8, api.SolidTexture(0.1, 0.1, 0.1)), 2.0,
+                                     api.SolidTexture(0.9, 0.5, 0.2))
+        g.push(med)
+        inner = api.HittableList()                                                    # a nested list: its scan continues the outer one
+        inner.push(api.Traslate(api.Cube((-0.3, -0.3, -0.3), (0.3, 0.3, 0.3), lam(0.3, 0.3, 0.9)), (cx + 0.7, cy - 0.3, cz + 0.3)))
+        inner.push(api.FlipNormals(api.ConstantMedium(api.Cube((cx - 0.2, cy + 0.2, cz - 0.6), (cx + 1.1, cy + 0.9, cz + 0.2), glass), 3.0,
+                                                      api.SolidTexture(0.9, 0.9, 0.3))))
+        g.push(api.FlipNormals(inner))
+        g.push(api.Rect(api.PLANE_XY, cx - 1.0, cy - 0.8, cx + 1.0, cy + 0.8, cz - 0.95, api.Metal(api.SolidTexture(0.8, 0.8, 0.8), 0.1)))
+        return g
+
+    objs = [api.Sphere((-4.0, 0.0, 0.0), 0.8, lam(0.7, 0.7, 0.2)), group(-1.5, 0.2, 0.0), api.Cube((0.4, -1.0, -0.6), (1.4, 0.2, 0.4), lam(0.3, 0.8, 0.8)),
+            api.FlipNormals(group(3.0, 0.3, -0.2, nested=True)), api.Sphere((5.2, 0.0, 0.5), 0.6, glass)]
+    w.push(api.BVHNode(objs, 0.0, 1.0))
+    w.push(api.BVHNode([group(-3.0, 3.0, -1.5)], 0.0, 1.0))                           # one element: the list is scanned — and draws — twice
+    tilted = api.BVHNode([group(0.0, 0.0, 0.0), api.Sphere((1.8, 0.0, 0.0), 0.5, lam(0.9, 0.9, 0.9)),
+                          api.ConstantMedium(api.Sphere((-1.8, 0.2, 0.0), 0.6, glass), 1.5, api.SolidTexture(0.6, 0.3, 0.9))], 0.0, 1.0)
+    w.push(api.Traslate(api.Rotate(api.AXIS_Y, tilted, 25.0), (1.5, 3.0, -1.0)))
+    return w
+
+
+def test_lists_with_media_lower_as_scan_groups(host):
+    a = host.lower(world_media_in_lists_in_bvh(host)).arrays()
+    items = a["items"]
+    B, M, E = abi.ITEMFLAG_LISTSCAN_BEGIN, abi.ITEMFLAG_LISTSCAN_MEMBER, abi.ITEMFLAG_LISTSCAN_END
+    ends = [k for k, it in enumerate(items) if it.flags & E]
+    begins = [k for k, it in enumerate(items) if it.flags & B]
+    assert len(begins) == len(ends) >= 5  # 2 + 2 (the one-element node) + 1, plus whatever BVHNode::new left alone in a slice of one
+    for b, e in zip(begins, ends):
+        grp = items[b:e]
+        assert b < e and all((it.flags & M) and (it.flags & abi.ITEMFLAG_DEFERRED) for it in grp) and not (items[e].flags & M)
+        assert items[e].kind == abi.ITEM_LIST and items[e].count == 0 and items[e].first >= 0
+        # sphere, medium, cube (own transform), medium (flipped twice: not flipped), rect
+        assert [bool(it.flags & abi.ITEMFLAG_MEDIUM) for it in grp] == [False, True, False, True, False]
+        assert [it.kind for it in grp] == [abi.ITEM_LIST] * 5 and all(it.count == 1 for it in grp)
+        # every member's gate is the holder's box: one box for the group
+        gates = {tuple(np.asarray(a["prim_gate"][it.first]).ravel()) for it in grp}
+        assert len(gates) == 1
+    assert sum(1 for it in items if (it.flags & M) and (it.flags & abi.ITEMFLAG_NESTED_MEDIUM)) >= 1
+    assert not any((it.flags & M) for k, it in enumerate(items) if not any(b <= k < e for b, e in zip(begins, ends)))
+
+
+def test_lists_with_media_mirror_equals_f64_oracle(host, orc64):
+    nx, ny = 48, 32
+    wh, wo = world_media_in_lists_in_bvh(host), world_media_in_lists_in_bvh(orc64)
+    ch, co = camera(host, nx, ny), camera(orc64, nx, ny)
+    for row in (8, 12, 16, 20, 24):
+        ref = orc64.render(co, wo, nx, ny, 1, seed=42, rows=(row, row + 1))
+        for i in range(nx):
+            c = host.color_sample(ch, wh, nx, ny, i, ny - 1 - row, 0, seed=42)
+            assert np.array_equal(c, ref["mean"][row, i]), (row, i)
+    orc64.free_all()
+
+
 def test_nested_media_lower_with_the_inner_density_behind_the_chain(host):
     a = host.lower(world_nested_media(host)).arrays()
     nested = [it for it in a["items"] if it.flags & abi.ITEMFLAG_NESTED_MEDIUM]
@@ -229,7 +301,8 @@ def test_instanced_subtrees_mirror_equals_f64_oracle(host, orc64):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("build", [world_media_in_bvh, world_instanced_subtrees, world_nested_media], ids=["media", "instanced_subtrees", "nested_media"])
+@pytest.mark.parametrize("build", [world_media_in_bvh, world_instanced_subtrees, world_nested_media, world_media_in_lists_in_bvh],
+                         ids=["media", "instanced_subtrees", "nested_media", "media_in_lists"])
 def test_every_kernel_equals_the_fp32_oracle(host, orc32, build):
     world_media_in_bvh = build  # noqa: F811 — the same comparison for both worlds
     nx, ny, ns = 120, 80, 24
