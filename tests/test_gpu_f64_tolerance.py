@@ -9,6 +9,7 @@ dielectric's reflect/refract draw — after which that ONE path of the pixel's n
 by (radiance of the path) / ns.  This test measures and bounds that on
   * BASELINE C3 cornell_box 800x800x1000 spp (the one lit BASELINE config), 64 evenly spaced rows = 51.2 M paths,
   * lit_final_scene 480x270x1000 spp (C5's object graph with the light the right way round), every 2nd row = 64.8 M paths,
+  * lit_smoke 800x800x1000 spp (C4's object graph and size with the back wall where the light can reach it), 64 rows = 51.2 M paths,
 in forked oracle workers (oracle/parallel.py).  The measured figures are printed, asserted with some slack, and quoted
 in DESIGN.md §6.  Reference loop: tests/test.rs:62-78."""
 import json
@@ -85,3 +86,19 @@ def test_lit_final_scene_against_the_f64_literal(host):
     assert r["share_within_1e-4"] >= 0.80 and r["share_within_1e-3"] >= 0.92 and r["share_within_1e-2"] >= 0.995
     assert r["mean_abs"] <= 5e-4 and r["max_abs"] <= 0.1
     assert r["ppm_values_differing"] <= 0.10 and r["ppm_values_differing_by_more_than_1"] <= 0.03 and r["ppm_max_level_diff"] <= 40
+
+
+def test_lit_smoke_fullsize_against_the_f64_literal(host):
+    """BASELINE C4's object graph and size (cornell_smoke 800x800x1000; the reference's own scene renders black: its back wall
+    sits at z = 0, tests/test.rs:369-377 — here at z = 555): the two ConstantMedium boxes put the fp32 logarithm and the
+    distance arithmetic of medium.rs:38-44 on most paths.  64 evenly spaced rows = 51.2 M paths."""
+    nx, ny, ns = 800, 800, 1000
+    rows = [int((k + 0.5) * ny / 64) for k in range(64)]
+    r = compare(host, "lit_smoke", nx, ny, ns, rows)
+    assert r["mean_radiance_f64"] > 0.3
+    # measured (MI355X, r04): image mean 1.8e-5 relative; 92.2 % of the channels within 1e-4, 96.5 % within 1e-3, 99.996 %
+    # within 1e-2; mean |d| 1.2e-4, max 0.0102; 2.6 % of the PPM values differ, 0.18 % by more than one level, at most 6
+    assert r["image_mean_rel_err"] <= 2e-4
+    assert r["share_within_1e-4"] >= 0.88 and r["share_within_1e-3"] >= 0.94 and r["share_within_1e-2"] >= 0.999
+    assert r["mean_abs"] <= 4e-4 and r["max_abs"] <= 0.05
+    assert r["ppm_values_differing"] <= 0.06 and r["ppm_values_differing_by_more_than_1"] <= 0.01 and r["ppm_max_level_diff"] <= 16
