@@ -116,7 +116,9 @@ def test_c2_random_spheres_under_the_sky_fullsize_against_the_f64_literal(host):
     assert r["mean_radiance_f64"] > 0.1
     # measured (MI355X, r04): image mean 7.6e-5 relative; 75.0 % of the channels within 1e-4, 95.1 % within 1e-3, 99.94 % within
     # 1e-2; mean |d| 1.9e-4, 99th percentile 1.9e-3, max 0.11; 4.1 % of the PPM values differ, 0.08 % by more than one level, at
-    # most 33 (500 spp: one flipped path moves a pixel twice as far as at 1000)
+    # most 33 (500 spp: one flipped path moves a pixel twice as far as at 1000).  The image-mean figure is systematic, not noise:
+    # the checker ground within 0.3 of the origin (radius-1000 sphere: its fp32 hit point's y is wrong by more than its size
+    # there, the checker's sin(10 y) flips) — DESIGN.md §6
     assert r["image_mean_rel_err"] <= 4e-4
     assert r["share_within_1e-4"] >= 0.68 and r["share_within_1e-3"] >= 0.92 and r["share_within_1e-2"] >= 0.995
     assert r["mean_abs"] <= 6e-4 and r["max_abs"] <= 0.5

@@ -1,0 +1,13 @@
+import sys, numpy as np, time
+sys.path.insert(0,'..'); sys.path.insert(0,'../tests')
+from oracle.parallel import render_parallel
+from oracle.oracle import SKY, ARITH_DEVICE, THROUGHPUT_FORM
+nx,ny,ns=1200,800,500
+rows=[int((k+0.5)*ny/64) for k in range(64)]
+for seed in (42,43,44):
+    t=time.time()
+    a=render_parallel("scenes_extra","random_spheres",nx,ny,ns,seed,ARITH_DEVICE|THROUGHPUT_FORM|SKY,precision="f32",rows=rows,workers=8,timeout=3000)
+    b=render_parallel("scenes_extra","random_spheres",nx,ny,ns,seed,SKY,precision="f64",rows=rows,workers=8,timeout=3000)
+    d=a["linear"][rows].astype(np.float64)-b["mean"][rows]
+    m=b["mean"][rows].mean()
+    print(seed, "rel signed mean diff %.3e"%(d.mean()/m), "upper half %.3e lower half %.3e"%(d[:32].mean()/b["mean"][rows][:32].mean(), d[32:].mean()/b["mean"][rows][32:].mean()), "t=%.0fs"%(time.time()-t), flush=True)
