@@ -1,5 +1,8 @@
+"""fp32 contract oracle vs f64 literal oracle on BASELINE C2 random_spheres under the opt-in sky: the signed image-mean
+offset per seed (diag_f64_bias_c2.py) and the first-hit albedo over the footprint of the biased patch (…_albedo.py).
+CPU only; DESIGN.md §6 quotes the result."""
 import sys, numpy as np, time
-sys.path.insert(0,'..'); sys.path.insert(0,'../tests')
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
 from oracle.parallel import render_parallel
 from oracle.oracle import SKY, ARITH_DEVICE, THROUGHPUT_FORM
 nx,ny,ns=1200,800,500
