@@ -66,6 +66,7 @@ struct rtmi_scene {
     int slots = 0;                  // CUs x 16: resident wavefronts the render kernels are launched with
     bool has_alt = false;           // some BVH item carries an alternative tree
     bool all_alt = false;           // every BVH item does (and there is one): the workgroup-cooperative kernel can run
+    bool needs_insd = false;        // DEFERRED items, list scans, nested media: the INSTL = 2 instantiations (rtmi_kernels.hpp)
     bool has_deferred = false;      // media that were children of a BVHNode (RTMI_ITEMFLAG_DEFERRED): the asynchronous
                                     // state-machine kernel does not carry them, RTMI_FLAG_ASYNC then runs the per-lane kernel
     uint32_t last_kernel = 0;       // RTMI_KERNEL_* of the last render enqueued on this handle (rtmi_stats.kernel)
@@ -486,6 +487,8 @@ extern "C" int rtmi_scene_create(const rtmi_scene_desc *d, int device, rtmi_scen
             s->dev.has_medium_outer = 1u; // (deferred media ride in the same instantiations as media inside transforms)
     for (uint32_t i = 0; i < d->n_items; i++)
         if (d->items[i].flags & (RTMI_ITEMFLAG_DEFERRED | RTMI_ITEMFLAG_NESTED_MEDIUM)) s->has_deferred = true;
+    for (uint32_t i = 0; i < d->n_items; i++)
+        if (d->items[i].flags & (RTMI_ITEMFLAG_SAVE_T0 | RTMI_ITEMFLAG_DEFERRED | RTMI_ITEMFLAG_NESTED_MEDIUM)) s->needs_insd = true;
     if (hipMalloc(reinterpret_cast<void **>(&s->status), RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess ||
         hipMemset(s->status, 0, RTMI_STATUS_WORDS * sizeof(unsigned int)) != hipSuccess) {
         rtmi_scene_destroy(s);
@@ -796,16 +799,22 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
         const uint32_t wps = wps_req;
         if (inst) { // instanced primitives, media inside transforms: their own instantiations (no diagnostics builds)
             if (prof) return fail(RTMI_ERR_UNSUPPORTED, "the profiling build has no instantiation for instanced primitives / media inside transforms");
-            if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, true);
-            else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, true);
-            else RTMI_LAUNCH_COOP(false, false, 4, false, true);
+            if (s->needs_insd) {
+                if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, 2);
+                else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, 2);
+                else RTMI_LAUNCH_COOP(false, false, 4, false, 2);
+            } else {
+                if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, 1);
+                else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, 1);
+                else RTMI_LAUNCH_COOP(false, false, 4, false, 1);
+            }
         }
-        else if (prof) RTMI_LAUNCH_COOP(false, true, 3, true, false);
-        else if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, false);
-        else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3, true, false);
-        else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5, true, false);
-        else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, false);
-        else RTMI_LAUNCH_COOP(false, false, 4, false, false);
+        else if (prof) RTMI_LAUNCH_COOP(false, true, 3, true, 0);
+        else if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, 0);
+        else if (wps == 3) RTMI_LAUNCH_COOP(false, false, 3, true, 0);
+        else if (wps == 5) RTMI_LAUNCH_COOP(false, false, 5, true, 0);
+        else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, 0);
+        else RTMI_LAUNCH_COOP(false, false, 4, false, 0);
     } else if (!async) {
         if (prof) { if (fast) RTMI_LAUNCH(rtmi_render_kernel, true, false, true, 0); else RTMI_LAUNCH(rtmi_render_kernel, false, false, true, 0); }
         else if (fast && sigf) RTMI_LAUNCH(rtmi_render_kernel, true, true, false, 0);

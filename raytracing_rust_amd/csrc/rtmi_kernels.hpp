@@ -175,9 +175,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void rtmi_render_kernel(DevSc
 // Same schedule as rtmi_render_kernel; the item scan of phase A is executed by ALL lanes (lanes
 // without a pending query are workers for the others' BVH traversals).
 // ----------------------------------------------------------------------------------
-// INST: instantiation for scenes with instanced primitives (rtmi.h); the others carry no transform code in their loops
-template <bool SIG, bool PROF, int WPS, bool EXT, bool INST>
+// INSTL: 0 = the instantiations of the common scenes: no transform code in their loops; 1 = scenes with instanced primitives or
+// media inside transforms (rtmi.h); 2 = also DEFERRED items, list scans, nested media (children of a BVHNode that are not
+// primitives).  Forced on the BASELINE scenes level 2 costs 10-14 % (profiles/r04_experiments/force_inst_ab.log), hence two levels.
+template <bool SIG, bool PROF, int WPS, bool EXT, int INSTL>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(DevScene sc, DevCamera cam, DevParams P) {
+    constexpr bool INST = INSTL >= 1; // instanced primitives, media inside transforms
+    constexpr bool INSD = INSTL >= 2; // DEFERRED items, list scans, nested media
     __shared__ unsigned long long prof_lds[PROF ? 2 * RTMI_PROF_SLOTS : 1];
     unsigned long long *prof = prof_lds;
     if (PROF) {
@@ -246,22 +250,22 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             W.o = pa.ro; W.d = pa.rd;
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
-            float t0_saved = RTMI_FLT_MAX; // INST: the closest hit before a BVH item whose media / instanced-subtree children follow as DEFERRED items
+            float t0_saved = RTMI_FLT_MAX; // INSD: the closest hit before a BVH item whose media / instanced-subtree children follow as DEFERRED items
             int grp_first = 0x7fffffff;    // ... the index of that item (or of the first deferred one), and whether it is the enclosing tree
             bool grp_tree = false;
-            ListScan ls; // INST: a list with media that was a child of a BVHNode (rtmi.h, LISTSCAN)
+            ListScan ls; // INSD: a list with media that was a child of a BVHNode (rtmi.h, LISTSCAN)
             ls.cl = RTMI_FLT_MAX; ls.item = -1; ls.pf = 0; ls.medium = false; ls.has = false;
             for (uint32_t it = 0; it < n_items; it++) { // executed by all 64 lanes
                 const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
-                if (INST && (I.flags & RTMI_ITEMFLAG_SAVE_T0)) {
+                if (INSD && (I.flags & RTMI_ITEMFLAG_SAVE_T0)) {
                     t0_saved = closest; grp_first = (int)it; grp_tree = I.kind == RTMI_ITEM_BVH && !(I.flags & RTMI_ITEMFLAG_DEFERRED);
                 }
-                if (INST && (I.flags & RTMI_ITEMFLAG_LISTSCAN_END)) { // wave-uniform: the terminator of a list scan
+                if (INSD && (I.flags & RTMI_ITEMFLAG_LISTSCAN_END)) { // wave-uniform: the terminator of a list scan
                     if (need) listscan_fold(ls, I.first, closest, best_item, best_pf, best_medium, grp_first, grp_tree);
                     continue;
                 }
-                if (INST && (I.flags & RTMI_ITEMFLAG_LISTSCAN_BEGIN)) { ls.cl = t0_saved; ls.has = false; }
-                const bool scan = INST && (I.flags & RTMI_ITEMFLAG_LISTSCAN_MEMBER) != 0u; // wave-uniform
+                if (INSD && (I.flags & RTMI_ITEMFLAG_LISTSCAN_BEGIN)) { ls.cl = t0_saved; ls.has = false; }
+                const bool scan = INSD && (I.flags & RTMI_ITEMFLAG_LISTSCAN_MEMBER) != 0u; // wave-uniform
                 RayF R = W;
                 if (I.xform_count > 0) { // both transforms of a chain of two in ONE scalar fetch (they follow the item record)
                     struct XPair { rtmi_xform x0, x1; };
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                             ls.cl = t; ls.item = (int)it; ls.pf = pf; ls.medium = false; ls.has = true;
                         }
                     } else
-                    if (INST && (I.flags & RTMI_ITEMFLAG_DEFERRED)) { // wave-uniform: an instanced subtree that was a child of a BVHNode (rtmi.h)
+                    if (INSD && (I.flags & RTMI_ITEMFLAG_DEFERRED)) { // wave-uniform: an instanced subtree that was a child of a BVHNode (rtmi.h)
                         const bool reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
                         if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, reach, R, pa.rtime, t_min, t0_saved, cw, t, pf, overflow, prof, slot) &&
                             deferred_bvh_wins(I.count, t, closest, best_item, best_pf, grp_first, grp_tree)) {
@@ -301,13 +305,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         h1 = false; h2 = false;
                         if (need) sphere_two_queries(R, make_float4(I.root_min[0], I.root_min[1], I.root_min[2], I.root_max[0]), h1, t1, h2, t2);
                     } else {
-                        // INST: a medium that was a child of a BVHNode (rtmi.h, DEFERRED) is reached through its parent's box
-                        const bool dfr = INST && (I.flags & RTMI_ITEMFLAG_DEFERRED) != 0u; // wave-uniform
+                        // INSD: a medium that was a child of a BVHNode (rtmi.h, DEFERRED) is reached through its parent's box
+                        const bool dfr = INSD && (I.flags & RTMI_ITEMFLAG_DEFERRED) != 0u; // wave-uniform
                         bool reach = need;
                         if (dfr) reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
                         h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, reach, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
                         h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, reach && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
-                        if (INST && (I.flags & RTMI_ITEMFLAG_NESTED_MEDIUM)) { // wave-uniform: the boundary is itself a medium (rtmi.h)
+                        if (INSD && (I.flags & RTMI_ITEMFLAG_NESTED_MEDIUM)) { // wave-uniform: the boundary is itself a medium (rtmi.h)
                             if (reach && h1 && h2) h1 = nested_medium_interval(sc, I, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), g, k0, k1, t1, t2);
                         }
                         if (dfr) { // its interval ends at the t_max the BVH was entered with; its hit must beat what the tree found
@@ -372,8 +376,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
 
 #ifndef RTMI_LEAN_TU
 // the lean instantiations (EXT = false) are compiled in rtmi_lean.hip, with another machine-scheduler strategy
-extern template __global__ void rtmi_render_coop<false, false, 4, false, false>(DevScene, DevCamera, DevParams);
-extern template __global__ void rtmi_render_coop<false, false, 4, false, true>(DevScene, DevCamera, DevParams);
+extern template __global__ void rtmi_render_coop<false, false, 4, false, 0>(DevScene, DevCamera, DevParams);
+extern template __global__ void rtmi_render_coop<false, false, 4, false, 1>(DevScene, DevCamera, DevParams);
+extern template __global__ void rtmi_render_coop<false, false, 4, false, 2>(DevScene, DevCamera, DevParams);
 #endif
 
 // ----------------------------------------------------------------------------------

@@ -15,5 +15,6 @@
 #define RTMI_LEAN_TU 1
 #include "rtmi_kernels.hpp"
 
-template __global__ void rtmi_render_coop<false, false, 4, false, false>(DevScene, DevCamera, DevParams);
-template __global__ void rtmi_render_coop<false, false, 4, false, true>(DevScene, DevCamera, DevParams);
+template __global__ void rtmi_render_coop<false, false, 4, false, 0>(DevScene, DevCamera, DevParams);
+template __global__ void rtmi_render_coop<false, false, 4, false, 1>(DevScene, DevCamera, DevParams);
+template __global__ void rtmi_render_coop<false, false, 4, false, 2>(DevScene, DevCamera, DevParams);
