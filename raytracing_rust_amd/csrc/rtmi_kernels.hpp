@@ -276,21 +276,23 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                 if (!(I.flags & RTMI_ITEMFLAG_MEDIUM)) {
                     float t;
                     int pf;
-                    if (scan) { // a primitive member of the list scan: t_max = the scan's closest hit so far
-                        const bool reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
-                        if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, reach, R, pa.rtime, t_min, ls.cl, cw, t, pf, overflow, prof, slot)) {
+                    // ONE query site (three inlined copies of the traversal made the INSD instantiations twice the code of the
+                    // others): a DEFERRED item — an instanced subtree that was a child of a BVHNode, or a primitive member of a
+                    // list scan (rtmi.h) — is reached through its gate and queried up to the t_max its group was entered with
+                    // (the scan's closest hit so far); what its hit means is decided afterwards
+                    bool reach = need;
+                    float qmax = closest;
+                    const bool dfi = INSD && (I.flags & RTMI_ITEMFLAG_DEFERRED) != 0u; // wave-uniform
+                    if (dfi) {
+                        reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
+                        qmax = scan ? ls.cl : t0_saved;
+                    }
+                    if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, reach, R, pa.rtime, t_min, qmax, cw, t, pf, overflow, prof, slot)) {
+                        if (scan) {
                             ls.cl = t; ls.item = (int)it; ls.pf = pf; ls.medium = false; ls.has = true;
-                        }
-                    } else
-                    if (INSD && (I.flags & RTMI_ITEMFLAG_DEFERRED)) { // wave-uniform: an instanced subtree that was a child of a BVHNode (rtmi.h)
-                        const bool reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
-                        if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, reach, R, pa.rtime, t_min, t0_saved, cw, t, pf, overflow, prof, slot) &&
-                            deferred_bvh_wins(I.count, t, closest, best_item, best_pf, grp_first, grp_tree)) {
+                        } else if (!dfi || deferred_bvh_wins(I.count, t, closest, best_item, best_pf, grp_first, grp_tree)) {
                             closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                         }
-                    } else
-                    if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, need, R, pa.rtime, t_min, closest, cw, t, pf, overflow, prof, slot)) {
-                        closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                     }
                     prof_time<PROF>(prof, I.kind == RTMI_ITEM_BVH ? (it == 0 ? 27 : 28) : 26, tstamp);
                 } else {
