@@ -765,7 +765,8 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
     // (test knob bit 11: a stack so small that rounds are throttled all the time — room for 64 visits when it is full)
     if (bcoop) P.coop_cap = (p->flags & (1u << 11)) ? 3u * RTMI_BLK_THREADS + 64u : RTMI_BLK_CAP;
     s->last_kernel = bcoop ? RTMI_KERNEL_BLOCK_COOP : coop ? RTMI_KERNEL_WAVE_COOP : async ? RTMI_KERNEL_ASYNC : RTMI_KERNEL_PERLANE;
-    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + (ext ? 0u : RTMI_RNG_RING_WORDS)) * sizeof(uint32_t);
+    const size_t coop_lds = (size_t)WAVES_PER_BLOCK * (2u * P.coop_cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + (ext ? 0u : RTMI_RNG_RING_WORDS) +
+                                                              ((inst && (s->needs_insd || ext || sigf)) ? RTMI_COOP_PARK_WORDS : 0u)) * sizeof(uint32_t);
     const uint32_t ntex = P.ntiles_local * 64u;
     uint32_t blocks_total = 0, chunks_total = 0;
     for (uint32_t s0 = 0; s0 < p->ns; s0 += pass_ns) { // one pass unless the sample buffer is smaller than ns samples
@@ -799,14 +800,16 @@ static int render_device_locked(rtmi_scene *s, const rtmi_camera *cam, const rtm
         const uint32_t wps = wps_req;
         if (inst) { // instanced primitives, media inside transforms: their own instantiations (no diagnostics builds)
             if (prof) return fail(RTMI_ERR_UNSUPPORTED, "the profiling build has no instantiation for instanced primitives / media inside transforms");
-            if (s->needs_insd) {
+            // level 2 (DEFERRED items, list scans, nested media; its group state parked in LDS) also serves the scenes that
+            // need level 1 only when they have trees: measured faster there than level 1's own instantiation (forced on
+            // final_scene -5.2 % against -7.8 %, random_spheres -3.4 % / -3.1 %); without trees level 1 is the faster one
+            // (cornell_box -9.5 % against -18 %) — profiles/r04_experiments/inst_levels_ab3_parked.log
+            if (s->needs_insd || ext || sigf) {
                 if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, 2);
                 else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, 2);
                 else RTMI_LAUNCH_COOP(false, false, 4, false, 2);
             } else {
-                if (sigf) RTMI_LAUNCH_COOP(true, false, 4, true, 1);
-                else if (ext) RTMI_LAUNCH_COOP(false, false, 4, true, 1);
-                else RTMI_LAUNCH_COOP(false, false, 4, false, 1);
+                RTMI_LAUNCH_COOP(false, false, 4, false, 1);
             }
         }
         else if (prof) RTMI_LAUNCH_COOP(false, true, 3, true, 0);

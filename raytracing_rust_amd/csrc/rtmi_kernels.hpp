@@ -193,7 +193,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
     const int wave = threadIdx.x >> 6;
     CoopWork cw;
     cw.cap = (int)P.coop_cap;
-    cw.wlds = lds_dyn + (size_t)wave * (2u * cw.cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + (EXT ? 0u : RTMI_RNG_RING_WORDS));
+    // per wave: pool | ctx | best | dummy | (lean: word ring) | (INSD: group state, RTMI_COOP_PARK_WORDS)
+    constexpr uint32_t lds_tail = (EXT ? 0u : RTMI_RNG_RING_WORDS) + (INSD ? RTMI_COOP_PARK_WORDS : 0u);
+    cw.wlds = lds_dyn + (size_t)wave * (2u * cw.cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + lds_tail);
+    // INSD: the state of a group of DEFERRED items lives in LDS, not in registers that would stay live through every
+    // traversal of every scene (parked: 20 VGPRs spilled -> see DESIGN.md §8d): per lane t0 | scan cl | scan holder | scan pf
+    uint32_t *park = cw.wlds + 2u * cw.cap + 64u * 12u + 128u + RTMI_COOP_DUMMY_WORDS + (EXT ? 0u : RTMI_RNG_RING_WORDS) + lane;
     cw.spill_cap = (int)P.spill_cap;
     cw.spill = P.spill + (size_t)(blockIdx.x * WAVES_PER_BLOCK + wave) * P.spill_cap;
     unsigned long long sig = 0ull;
@@ -250,21 +255,27 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
             W.o = pa.ro; W.d = pa.rd;
             ray_derive(W);
             if (need) { closest = RTMI_FLT_MAX; best_item = -1; best_pf = 0; best_medium = false; }
-            float t0_saved = RTMI_FLT_MAX; // INSD: the closest hit before a BVH item whose media / instanced-subtree children follow as DEFERRED items
-            int grp_first = 0x7fffffff;    // ... the index of that item (or of the first deferred one), and whether it is the enclosing tree
+            // INSD, parked in LDS: [0] the closest hit before a BVH item whose media / instanced-subtree children follow as DEFERRED
+            // items (T0); [64] / [128] / [192] the scan of a list with media that was a child of a BVHNode (rtmi.h, LISTSCAN): its
+            // closest hit so far, who holds it (item, bit 31: a medium; RTMI_PARK_NONE: nobody) and the primitive
+            int grp_first = 0x7fffffff;    // the index of the SAVE_T0 item (or of the first deferred one), and whether it is the enclosing tree
             bool grp_tree = false;
-            ListScan ls; // INSD: a list with media that was a child of a BVHNode (rtmi.h, LISTSCAN)
-            ls.cl = RTMI_FLT_MAX; ls.item = -1; ls.pf = 0; ls.medium = false; ls.has = false;
+            if (INSD) park[0] = __float_as_uint(RTMI_FLT_MAX);
             for (uint32_t it = 0; it < n_items; it++) { // executed by all 64 lanes
                 const rtmi_item I = RTMI_UNIFORM_LOAD(rtmi_item, &sc.items[it].it);
                 if (INSD && (I.flags & RTMI_ITEMFLAG_SAVE_T0)) {
-                    t0_saved = closest; grp_first = (int)it; grp_tree = I.kind == RTMI_ITEM_BVH && !(I.flags & RTMI_ITEMFLAG_DEFERRED);
+                    park[0] = __float_as_uint(closest); grp_first = (int)it; grp_tree = I.kind == RTMI_ITEM_BVH && !(I.flags & RTMI_ITEMFLAG_DEFERRED);
                 }
                 if (INSD && (I.flags & RTMI_ITEMFLAG_LISTSCAN_END)) { // wave-uniform: the terminator of a list scan
-                    if (need) listscan_fold(ls, I.first, closest, best_item, best_pf, best_medium, grp_first, grp_tree);
+                    const uint32_t holder = park[128];
+                    if (need && holder != RTMI_PARK_NONE) {
+                        ListScan ls;
+                        ls.cl = __uint_as_float(park[64]); ls.item = (int)(holder & 0x7fffffffu); ls.pf = (int)park[192]; ls.medium = (holder >> 31) != 0u; ls.has = true;
+                        listscan_fold(ls, I.first, closest, best_item, best_pf, best_medium, grp_first, grp_tree);
+                    }
                     continue;
                 }
-                if (INSD && (I.flags & RTMI_ITEMFLAG_LISTSCAN_BEGIN)) { ls.cl = t0_saved; ls.has = false; }
+                if (INSD && (I.flags & RTMI_ITEMFLAG_LISTSCAN_BEGIN)) { park[64] = park[0]; park[128] = RTMI_PARK_NONE; }
                 const bool scan = INSD && (I.flags & RTMI_ITEMFLAG_LISTSCAN_MEMBER) != 0u; // wave-uniform
                 RayF R = W;
                 if (I.xform_count > 0) { // both transforms of a chain of two in ONE scalar fetch (they follow the item record)
@@ -284,12 +295,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                     float qmax = closest;
                     const bool dfi = INSD && (I.flags & RTMI_ITEMFLAG_DEFERRED) != 0u; // wave-uniform
                     if (dfi) {
+                        const float t0_saved = __uint_as_float(park[0]);
                         reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
-                        qmax = scan ? ls.cl : t0_saved;
+                        qmax = scan ? __uint_as_float(park[64]) : t0_saved;
                     }
                     if (geom_query_coop<PROF, EXT, EXT, INST>(sc, I, use_alt, reach, R, pa.rtime, t_min, qmax, cw, t, pf, overflow, prof, slot)) {
                         if (scan) {
-                            ls.cl = t; ls.item = (int)it; ls.pf = pf; ls.medium = false; ls.has = true;
+                            park[64] = __float_as_uint(t); park[128] = it; park[192] = (uint32_t)pf;
                         } else if (!dfi || deferred_bvh_wins(I.count, t, closest, best_item, best_pf, grp_first, grp_tree)) {
                             closest = t; best_item = (int)it; best_pf = pf; best_medium = false;
                         }
@@ -310,15 +322,19 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, WPS) void rtmi_render_coop(De
                         // INSD: a medium that was a child of a BVHNode (rtmi.h, DEFERRED) is reached through its parent's box
                         const bool dfr = INSD && (I.flags & RTMI_ITEMFLAG_DEFERRED) != 0u; // wave-uniform
                         bool reach = need;
-                        if (dfr) reach = need && deferred_gate(sc, I, W, t_min, t0_saved);
+                        float t0_saved = RTMI_FLT_MAX;
+                        if (dfr) {
+                            t0_saved = scan ? __uint_as_float(park[64]) : __uint_as_float(park[0]); // the interval's end: the scan's closest hit, or T0
+                            reach = need && deferred_gate(sc, I, W, t_min, __uint_as_float(park[0]));
+                        }
                         h1 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, reach, R, pa.rtime, -RTMI_FLT_MAX, RTMI_FLT_MAX, cw, t1, pf, overflow, prof, slot);
                         h2 = geom_query_coop<PROF, EXT, false, INST>(sc, I, use_alt, reach && h1, R, pa.rtime, t1 + 0.0001f, RTMI_FLT_MAX, cw, t2, pf, overflow, prof, slot);
                         if (INSD && (I.flags & RTMI_ITEMFLAG_NESTED_MEDIUM)) { // wave-uniform: the boundary is itself a medium (rtmi.h)
                             if (reach && h1 && h2) h1 = nested_medium_interval(sc, I, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), g, k0, k1, t1, t2);
                         }
                         if (dfr) { // its interval ends at the t_max the BVH was entered with; its hit must beat what the tree found
-                            if (reach && h1 && h2 && medium_sample(t1, t2, t_min, scan ? ls.cl : t0_saved, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
-                                if (scan) { ls.cl = tm; ls.item = (int)it; ls.medium = true; ls.has = true; }
+                            if (reach && h1 && h2 && medium_sample(t1, t2, t_min, t0_saved, medium_dir_norm<INST>(sc, I.flags, I.xform_first, W), I.neg_inv_density, g, k0, k1, tm)) {
+                                if (scan) { park[64] = __float_as_uint(tm); park[128] = it | 0x80000000u; }
                                 else if (tm < closest) { closest = tm; best_item = (int)it; best_medium = true; }
                             }
                             h1 = false; // done

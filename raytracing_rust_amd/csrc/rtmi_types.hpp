@@ -117,6 +117,8 @@ struct DevParams {
 // device-only item flag (set by rtmi_scene_create, never part of the ABI): MEDIUM item whose boundary is one static
 // sphere; root_min = its centre, root_max[0] = its radius
 #define RTMI_ITEMFLAG_DEV_MEDIUM_SPHERE (1u << 16)
+#define RTMI_COOP_PARK_WORDS 256u   /* cooperative kernel, INSD instantiations: 4 words per lane of group state in LDS */
+#define RTMI_PARK_NONE 0x7fffffffu  /* ... no member of the list scan holds a hit */
 #define RTMI_EXT_FACE_FORWARD 1u  // RTMI_FLAG_FACE_FORWARD
 #define RTMI_EXT_UV_BOOK 2u       // RTMI_FLAG_UV_BOOK
 #define RTMI_EXT_TEST_OVERFLOW 4u // RTMI_FLAG_TEST_OVERFLOW
