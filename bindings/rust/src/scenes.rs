@@ -164,19 +164,40 @@ pub fn media_in_bvh(seed: u64) -> Rc<HittableDesc> {
     let mut inner_list = vec![
         sphere([-4.5, 1.2, 1.5], 0.5, grey.clone()),
         constant_medium(sphere([-4.2, 1.3, 1.4], 1.0, glass.clone()), 1.0, solid_texture(0.4, 0.9, 0.6)),
-        cube([-5.6, 0.2, 0.8], [-5.0, 0.9, 1.6], grey),
+        cube([-5.6, 0.2, 0.8], [-5.0, 0.9, 1.6], grey.clone()),
     ];
     // (construction order = the order of the scene stream's draws in the twin: sub, inner, then the rest)
     let inner = bvh_new(&mut inner_list, 0.0, 1.0, &mut s.backend);
     let bvh = bvh_new(&mut objs, 0.0, 1.0, &mut s.backend);
     let mut one_bvh = vec![inner];
     let over_inner = bvh_new(&mut one_bvh, 0.0, 1.0, &mut s.backend);
-    let mut one_medium = vec![constant_medium(sphere([0.0, 2.6, -1.5], 0.8, glass), 1.2, solid_texture(0.9, 0.8, 0.2))];
+    let mut one_medium = vec![constant_medium(sphere([0.0, 2.6, -1.5], 0.8, glass.clone()), 1.2, solid_texture(0.9, 0.8, 0.2))];
     let over_medium = bvh_new(&mut one_medium, 0.0, 1.0, &mut s.backend);
+    // a nested medium (one item, the inner density behind its chain) ...
+    // (the same two material objects as above: materials are numbered by identity, as in the C++ lowering)
+    let nested = constant_medium(
+        constant_medium(sphere([5.0, 3.0, -2.0], 0.7, glass.clone()), 0.8, solid_texture(0.1, 0.1, 0.1)),
+        2.0,
+        solid_texture(0.9, 0.5, 0.2),
+    );
+    // ... and a HittableList WITH MEDIA as a child of a BVHNode: a group of LISTSCAN members and a terminator behind the BVH item
+    let inner_l = hittable_list(vec![
+        traslate(cube([-0.3, -0.3, -0.3], [0.3, 0.3, 0.3], grey.clone()), [6.9, -0.2, 2.1]),
+        constant_medium(cube([6.0, 0.3, 1.2], [7.0, 0.9, 2.0], glass.clone()), 3.0, solid_texture(0.9, 0.9, 0.3)),
+    ]);
+    let lst = hittable_list(vec![
+        sphere([6.0, 0.0, 2.0], 0.4, grey.clone()),
+        constant_medium(sphere([6.3, 0.1, 1.8], 0.8, glass), 2.0, solid_texture(0.3, 0.9, 0.4)),
+        flip_normals(inner_l),
+    ]);
+    let mut over_list_items = vec![lst, sphere([8.0, 0.0, 2.0], 0.5, grey)];
+    let over_list = bvh_new(&mut over_list_items, 0.0, 1.0, &mut s.backend);
     hittable_list(vec![
         traslate(rotate(AXIS_Y, bvh, -30.0), [-1.0, 1.2, 3.0]),
         over_inner,
         over_medium,
+        nested,
+        over_list,
         sphere([0.0, 9.0, 0.0], 2.0, diffuse_light(solid_texture(4.0, 4.0, 4.0))),
     ])
 }

@@ -112,7 +112,8 @@ def media_in_bvh(api, seed=1):
     and media inside Traslate(Rotate(..)) — one medium around a plain boundary, one itself inside a Traslate, and an instanced
     subtree (Traslate(Rotate(BVHNode))) —, a BVHNode
     over ONE object that is a BVH with a medium in it (evaluated on both sides: its medium twice), and a BVHNode over one
-    medium (no primitives at all: no BVH item, the first deferred item remembers T0 itself)."""
+    medium (no primitives at all: no BVH item, the first deferred item remembers T0 itself); a nested medium; a list with media
+    (and a nested flipped list) as a child of a BVHNode."""
     api.seed_scene_rng(seed)
     grey = api.Lambertian(api.SolidTexture(0.7, 0.7, 0.7))
     glass = api.Dielectric(1.5)
@@ -131,6 +132,18 @@ def media_in_bvh(api, seed=1):
     world.push(api.Traslate(api.Rotate(api.AXIS_Y, api.BVHNode(objs, 0.0, 1.0), -30.0), (-1.0, 1.2, 3.0)))
     world.push(api.BVHNode([inner], 0.0, 1.0))
     world.push(api.BVHNode([api.ConstantMedium(api.Sphere((0.0, 2.6, -1.5), 0.8, glass), 1.2, api.SolidTexture(0.9, 0.8, 0.2))], 0.0, 1.0))
+    # a nested medium (one item, the inner density behind its chain) ...
+    world.push(api.ConstantMedium(api.ConstantMedium(api.Sphere((5.0, 3.0, -2.0), 0.7, glass), 0.8, api.SolidTexture(0.1, 0.1, 0.1)), 2.0,
+                                  api.SolidTexture(0.9, 0.5, 0.2)))
+    # ... and a HittableList WITH MEDIA as a child of a BVHNode: a group of LISTSCAN members and a terminator behind the BVH item
+    inner_l = api.HittableList()
+    inner_l.push(api.Traslate(api.Cube((-0.3, -0.3, -0.3), (0.3, 0.3, 0.3), grey), (6.9, -0.2, 2.1)))
+    inner_l.push(api.ConstantMedium(api.Cube((6.0, 0.3, 1.2), (7.0, 0.9, 2.0), glass), 3.0, api.SolidTexture(0.9, 0.9, 0.3)))
+    lst = api.HittableList()
+    lst.push(api.Sphere((6.0, 0.0, 2.0), 0.4, grey))
+    lst.push(api.ConstantMedium(api.Sphere((6.3, 0.1, 1.8), 0.8, glass), 2.0, api.SolidTexture(0.3, 0.9, 0.4)))
+    lst.push(api.FlipNormals(inner_l))
+    world.push(api.BVHNode([lst, api.Sphere((8.0, 0.0, 2.0), 0.5, grey)], 0.0, 1.0))
     world.push(api.Sphere((0.0, 9.0, 0.0), 2.0, api.DiffuseLight(api.SolidTexture(4.0, 4.0, 4.0))))
     return world
 
