@@ -345,7 +345,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=0)
     ap.add_argument("--shade-threshold", type=int, default=0)
     ap.add_argument("--cpu-rows", type=int, default=16)
-    ap.add_argument("--cpu-spp", type=int, default=320)  # x 16 rows x 1920 px = 9.8 M samples: about 30 s of one core
+    ap.add_argument("--cpu-spp", type=int, default=352)  # x 16 rows x 1920 px = 10.8 M samples: a little over 30 s of one core
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, one GPU per rank) for real runs; gloo only to rehearse N > 1 on a box with "
