@@ -139,3 +139,50 @@ def test_checker_nesting_depth_is_bounded_loudly(host):
     assert _rc(host.lower(world_with(16)).desc())[0] in (0, 3)
     rc, msg = _rc(host.lower(world_with(17)).desc())
     assert rc == 1 and "nested deeper" in msg
+
+
+def test_group_flags_of_deferred_items_are_validated(host):
+    """ABI 7's item flags for children of a BVHNode that are not primitives (rtmi.h): a list scan is BEGIN on its first member,
+    MEMBER on every item up to the terminator and on no other, one END terminator (kind LIST, no primitives); a NESTED_MEDIUM
+    item is a MEDIUM with its RTMI_XF_INNER_MEDIUM record behind its chain; all of them are DEFERRED where the header says so."""
+    import sys
+    import os
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    import dump_flat_scene
+
+    sc = host.lower(dump_flat_scene.media_in_bvh(host, 1))
+    d = sc.desc()
+    a = _private(d)
+    assert _rc(d)[0] in (0, 3)
+    items = a["items"]
+    n = d.n_items
+    B, M, E = abi.ITEMFLAG_LISTSCAN_BEGIN, abi.ITEMFLAG_LISTSCAN_MEMBER, abi.ITEMFLAG_LISTSCAN_END
+    begin = next(k for k in range(n) if items[k].flags & B)
+    end = next(k for k in range(n) if items[k].flags & E)
+    nested = next(k for k in range(n) if (items[k].flags & abi.ITEMFLAG_NESTED_MEDIUM) and not (items[k].flags & abi.ITEMFLAG_DEFERRED))
+    assert begin < end and all(items[k].flags & M for k in range(begin, end))
+
+    def broken(k, field, value):
+        old = getattr(items[k], field)
+        setattr(items[k], field, value)
+        rc, msg = _rc(d)
+        setattr(items[k], field, old)
+        return rc == 1 and bool(msg)
+
+    assert broken(begin, "flags", items[begin].flags & ~B)                       # members without a BEGIN
+    assert broken(begin + 1, "flags", items[begin + 1].flags & ~M)               # a non-member inside the group
+    assert broken(begin + 1, "flags", items[begin + 1].flags | B)                # a second BEGIN inside
+    assert broken(end, "flags", items[end].flags & ~E)                           # no terminator (and a LIST item of no primitives that is DEFERRED)
+    assert broken(end, "count", 1)                                               # a terminator with primitives
+    assert broken(end, "flags", items[end].flags & ~abi.ITEMFLAG_DEFERRED)       # LISTSCAN without DEFERRED
+    assert broken(begin - 1, "flags", items[begin - 1].flags | M) or begin == 0  # a member outside any group
+    assert broken(nested, "flags", items[nested].flags & ~abi.ITEMFLAG_MEDIUM)   # NESTED_MEDIUM on a non-medium
+    xf = a["xf"]
+    at = items[nested].xform_first + items[nested].xform_count
+    old = xf[at].kind
+    xf[at].kind = abi.XF_TRANSLATE                                               # its inner-medium record replaced
+    rc, msg = _rc(d)
+    xf[at].kind = old
+    assert rc == 1 and msg
+    assert _rc(d)[0] in (0, 3)
